@@ -1,0 +1,236 @@
+/*
+ * particles_hip.h — C ABI of the MI355X (gfx950) particle-update library.
+ *
+ * This is the drop-in boundary for the per-frame particle update that
+ * sphereflow/particles runs in src/compute.wgsl behind `pub struct Compute`
+ * (reference: src/compute.rs:11-22).  Every entry point is `extern "C"`, takes
+ * plain pointers and sizes, returns an int status (0 = ok, negative = error)
+ * and never throws or aborts.  A handle owns all of its device memory and is
+ * used by one caller at a time (the reference's `&mut self`); different
+ * handles are independent.  Host pointers passed in are only read or written
+ * during the call.  `pcl_step*` calls are asynchronous on the handle's HIP
+ * stream; every call that returns data to the host synchronises that stream.
+ *
+ * Each declaration cites the reference interface it replaces
+ * (file:line relative to the reference checkout).
+ */
+#ifndef PARTICLES_HIP_H
+#define PARTICLES_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* POD layouts shared with the reference (bit-for-bit).                */
+/* ------------------------------------------------------------------ */
+
+/* One particle record, 48 bytes.  src/main.rs:76-83, src/compute.wgsl:1-5. */
+typedef struct pcl_particle {
+    float    pos[4];  /* xyz + w (the kernel writes w = 1.0)          @0  */
+    float    vel[4];  /* xyz + w (the kernel writes w = 1.0)          @16 */
+    uint32_t ty;      /* particle type, 0..4                          @32 */
+    uint32_t pad[3];  /*                                              @36 */
+} pcl_particle;
+
+/* Force-curve polynomial, coeffs[i] multiplies x^i.  src/poly7.rs:6-10,
+ * src/compute.wgsl:40-49 (fields h,g,f,e,d,c,b,a = coeffs[0..8]). */
+typedef struct pcl_poly7 {
+    float coeffs[8];
+} pcl_poly7;
+
+/* Mass padded to a 16-byte array stride.  src/main.rs:196-201,
+ * src/compute.wgsl:8-10. */
+typedef struct pcl_mass_wrap {
+    float mass;
+    float pad[3];
+} pcl_mass_wrap;
+
+#define PCL_NUM_TYPES 5
+#define PCL_NUM_POLYS 25
+
+/* The 912-byte uniform block.  src/sim_params.rs:6-17,
+ * src/compute.wgsl:17-28. */
+typedef struct pcl_sim_params {
+    pcl_poly7     attraction_force[PCL_NUM_POLYS];      /* @0   */
+    pcl_mass_wrap particle_type_masses[PCL_NUM_TYPES];  /* @800 */
+    uint32_t      force_grid_dimensions[3];             /* @880 */
+    float         delta_t;                              /* @892 */
+    float         max_velocity;                         /* @896 */
+    float         bounding_volume_radius;               /* @900 */
+    float         cut_off_distance;                     /* @904 */
+    float         distance_exponent;                    /* @908 */
+} pcl_sim_params;
+
+/* Per-step diagnostics (no counterpart in the reference, which never reads
+ * particle state back; requested for the multi-GPU all-reduce). 48 bytes;
+ * the same layout is used for the device-resident copy. */
+typedef struct pcl_diagnostics {
+    double count;           /* number of particles reduced (exact integer)  @0  */
+    double kinetic_energy;  /* sum 0.5*m*|v|^2, accumulated in f64          @8  */
+    float  pos_max[3];      /* max x, y, z                                  @16 */
+    float  neg_pos_min[3];  /* -(min x), -(min y), -(min z): max-reducible  @28 */
+    float  pad[2];          /*                                              @40 */
+} pcl_diagnostics;
+
+typedef struct pcl_compute pcl_compute; /* opaque handle */
+
+/* Status codes. */
+enum {
+    PCL_OK               = 0,
+    PCL_ERR_INVALID      = -1, /* bad argument (null pointer, size mismatch, ty >= 5, ...) */
+    PCL_ERR_HIP          = -2, /* a HIP runtime call failed; see pcl_last_error()          */
+    PCL_ERR_NO_DEVICE    = -3, /* no usable gfx950 device                                  */
+    PCL_ERR_OUT_OF_RANGE = -4  /* first/count outside the particle or cell range           */
+};
+
+/* Which kernel family pcl_step picked (see pcl_last_step_kernel). */
+enum {
+    PCL_KERNEL_NONE      = 0,
+    PCL_KERNEL_STREAM    = 1, /* pair term provably zero: streaming kernel        */
+    PCL_KERNEL_PAIRS     = 2  /* general kernel with the all-pairs attraction loop */
+};
+
+/* Thread-local description of the last failure on the calling thread. */
+const char* pcl_last_error(void);
+
+/* Number of HIP devices visible; negative status on failure. */
+int pcl_device_count(void);
+
+/* Default parameter block.  Replaces SimParams::new(), src/sim_params.rs:20-31. */
+void pcl_sim_params_default(pcl_sim_params* out);
+
+/*
+ * Construct.  Replaces Compute::new(device, particles, force_grid),
+ * src/compute.rs:25-145: copies both inputs, parameters start as
+ * SimParams::new() (delta_t = 0) exactly as compute.rs:33 does.
+ * `n` may be 0.  `n_cells` is only checked against the parameter block's
+ * dimensions when a step is launched (the reference never checks; an index
+ * past the end is clamped to the last cell).
+ */
+int pcl_create(const pcl_particle* particles, size_t n,
+               const float (*force_grid)[4], size_t n_cells,
+               int device, pcl_compute** out);
+
+/* Drop.  Replaces the implicit Drop of Compute (wgpu buffers freed). */
+int pcl_destroy(pcl_compute* h);
+
+/* Replaces Compute::upload_particles, src/compute.rs:182-196: replaces the
+ * whole particle set and N.  The ping-pong position is not reset. */
+int pcl_upload_particles(pcl_compute* h, const pcl_particle* particles, size_t n);
+
+/* Structure-of-arrays upload of the same data (host arrays of length n;
+ * `ty` one byte per particle). Extension of compute.rs:182 for callers that
+ * already hold SoA state. */
+int pcl_upload_particles_soa(pcl_compute* h, size_t n,
+                             const float* x, const float* y, const float* z,
+                             const float* vx, const float* vy, const float* vz,
+                             const uint8_t* ty);
+
+/* Fill the particle set on the device with the seeded synthetic scene used
+ * by the benchmark (no counterpart in the reference, whose generator is
+ * unseeded: src/main.rs:41-48,156-169 give the distribution).  Particle i
+ * gets global index first_global_index + i; pos = pos_extent * (u - 0.5),
+ * vel = vel_extent * (u - 0.5) per axis with u in [0,1) drawn from a
+ * counter-based hash of (seed, global index, axis); ty = global index % 5. */
+int pcl_generate_particles(pcl_compute* h, size_t n, uint64_t seed,
+                           uint64_t first_global_index,
+                           float pos_extent, float vel_extent);
+
+/* Replaces Compute::update_force_grid, src/compute.rs:198-204: whole-field
+ * replace from host memory. */
+int pcl_update_force_grid(pcl_compute* h, const float (*force_grid)[4], size_t n_cells);
+
+/* Same, from device memory on the handle's device (e.g. the receive buffer
+ * of an RCCL broadcast). Ordered on the handle's stream. */
+int pcl_update_force_grid_device(pcl_compute* h, const void* dev_force_grid, size_t n_cells);
+
+/* Partial field update for brush edits: cells [first_cell, first_cell+count).
+ * Replaces the per-frame whole-field re-upload of src/main.rs:371-380. */
+int pcl_patch_force_grid(pcl_compute* h, size_t first_cell,
+                         const float (*cells)[4], size_t count);
+int pcl_patch_force_grid_device(pcl_compute* h, size_t first_cell,
+                                const void* dev_cells, size_t count);
+
+/* Replaces Compute::update_sim_params, src/compute.rs:206-219.  delta_t
+ * travels in the block, as in the reference. */
+int pcl_update_sim_params(pcl_compute* h, const pcl_sim_params* params);
+
+/* Replaces Compute::compute, src/compute.rs:221-227: one update of every
+ * particle from the current buffer into the other one, then flip. */
+int pcl_step(pcl_compute* h);
+
+/* Convenience: set delta_t, then pcl_step. */
+int pcl_step_dt(pcl_compute* h, float delta_t);
+
+/* Force the general (pair-loop) kernel even when the pair term is provably
+ * zero; for equivalence tests.  0 = automatic choice (default). */
+int pcl_force_pair_kernel(pcl_compute* h, int enable);
+
+/* PCL_KERNEL_* of the most recent step. */
+int pcl_last_step_kernel(const pcl_compute* h);
+
+/* When enabled, every step also reduces diagnostics of the state it writes
+ * (fused into the step kernel, no extra pass over HBM). */
+int pcl_enable_step_diagnostics(pcl_compute* h, int enable);
+
+/* Replaces the public field Compute::num_particles, src/compute.rs:19. */
+size_t pcl_num_particles(const pcl_compute* h);
+
+/* Number of steps taken since creation. */
+uint64_t pcl_step_count(const pcl_compute* h);
+
+/* Read back AoS records of the latest state, caller order
+ * (the reference exposes particles_buffers, src/compute.rs:13, stride 48,
+ * pos @0, ty @32: src/main.rs:86-107).  pos.w and vel.w read back as 1.0. */
+int pcl_read_particles(pcl_compute* h, pcl_particle* out, size_t first, size_t count);
+
+/* Read back SoA arrays of the latest state (any pointer may be NULL). */
+int pcl_read_soa(pcl_compute* h, size_t first, size_t count,
+                 float* x, float* y, float* z,
+                 float* vx, float* vy, float* vz, uint8_t* ty);
+
+/* Pack the latest state into a device buffer of 48-byte records, the
+ * renderer's instance layout (src/main.rs:86-107, src/renderer.rs:253-257). */
+int pcl_pack_particles_device(pcl_compute* h, void* dev_out, size_t first, size_t count);
+
+/* Diagnostics of the latest state, synchronous.  Uses the fused result when
+ * step diagnostics are enabled and current, otherwise runs a reduction. */
+int pcl_diagnostics_read(pcl_compute* h, pcl_diagnostics* out);
+
+/* Same, written asynchronously to `dev_out` (48 bytes of device memory),
+ * ordered on the handle's stream: the input of the per-step all-reduce. */
+int pcl_diagnostics_device(pcl_compute* h, void* dev_out);
+
+/* Flat field-cell index of every particle's current position
+ * (src/compute.wgsl:81-89,147), for bit-exact index tests. */
+int pcl_debug_cell_indices(pcl_compute* h, uint32_t* out, size_t first, size_t count);
+
+/* Run subsequent work of this handle on `hip_stream` (a hipStream_t owned by
+ * the caller, e.g. torch's current stream); NULL restores the internal one. */
+int pcl_set_stream(pcl_compute* h, void* hip_stream);
+
+/* Block until the handle's stream is idle. */
+int pcl_synchronize(pcl_compute* h);
+
+/* HIP-event stopwatch on the handle's stream: start records an event, stop
+ * records another, waits for it and returns the elapsed milliseconds. */
+int pcl_timer_start(pcl_compute* h);
+int pcl_timer_stop(pcl_compute* h, float* elapsed_ms);
+
+/* Geometry of the streaming kernel's launch (for reports). */
+int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks,
+                        uint32_t* block_threads, uint32_t* particles_per_lane);
+
+/* Tuning knobs of the streaming kernel (0 keeps the built-in default):
+ * grid_blocks caps the persistent grid; variant selects a code variant. */
+int pcl_set_tuning(pcl_compute* h, uint32_t grid_blocks, uint32_t variant);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* PARTICLES_HIP_H */

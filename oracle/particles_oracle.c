@@ -1,0 +1,448 @@
+/*
+ * particles_oracle.c — CPU restatement of the reference's particle update.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the shipped library or its Python
+ * host layer links, imports or calls this file; it is the checker used by
+ * tests/, by __graft_entry__.smoke() and by the cpu_baseline leg of bench.py.
+ *
+ * PARITY UNPINNED.  The reference (sphereflow/particles) is Rust + WGSL with
+ * no tests, fixtures or golden vectors, and it cannot be built or run in this
+ * environment (no rustc/cargo, no WGSL compiler, no Vulkan loader).  All of
+ * the path's arithmetic is in src/compute.wgsl, which this file transcribes
+ * statement by statement; what wgpu 0.18.0 / naga 0.14.2 (Cargo.lock) add on
+ * top — the precision of exp/pow/sqrt/normalize/divide, FMA contraction and
+ * the out-of-bounds policy for the field fetch — is implementation-defined
+ * there and is frozen here as follows:
+ *
+ *   length(v)    = sqrtf((v.x*v.x + v.y*v.y) + v.z*v.z)
+ *   normalize(v) = v / length(v)                (three IEEE divides)
+ *   pow, exp     = powf, expf (libm)
+ *   clamp(x,a,b) = fminf(fmaxf(x, a), b)
+ *   u32(f)       = truncation (f is always within [0, dim] here)
+ *   no FMA contraction (build with -ffp-contract=off)
+ *   field index past the end -> last cell (naga's "Restrict" bounds policy)
+ *   inputs are finite and ty < 5
+ *
+ * Function-by-function citations are relative to the reference checkout.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- layouts: src/main.rs:76-83, src/main.rs:196-201, src/poly7.rs:6-10,
+ *      src/sim_params.rs:6-17 (mirrored by src/compute.wgsl:1-28,40-49) ---- */
+typedef struct {
+    float    pos[4];
+    float    vel[4];
+    uint32_t ty;
+    uint32_t pad[3];
+} orc_particle;
+
+typedef struct { float coeffs[8]; } orc_poly7;
+typedef struct { float mass; float pad[3]; } orc_mass_wrap;
+
+typedef struct {
+    orc_poly7     attraction_force[25];
+    orc_mass_wrap particle_type_masses[5];
+    uint32_t      force_grid_dimensions[3];
+    float         delta_t;
+    float         max_velocity;
+    float         bounding_volume_radius;
+    float         cut_off_distance;
+    float         distance_exponent;
+} orc_sim_params;
+
+typedef struct {
+    double count;
+    double kinetic_energy;
+    float  pos_max[3];
+    float  neg_pos_min[3];
+    float  pad[2];
+} orc_diagnostics;
+
+_Static_assert(sizeof(orc_particle) == 48, "Particle is 48 bytes");
+_Static_assert(offsetof(orc_particle, vel) == 16, "vel @16");
+_Static_assert(offsetof(orc_particle, ty) == 32, "ty @32");
+_Static_assert(sizeof(orc_poly7) == 32, "Poly7 is 32 bytes");
+_Static_assert(sizeof(orc_mass_wrap) == 16, "MassWrap is 16 bytes");
+_Static_assert(sizeof(orc_sim_params) == 912, "SimParams is 912 bytes");
+_Static_assert(offsetof(orc_sim_params, particle_type_masses) == 800, "masses @800");
+_Static_assert(offsetof(orc_sim_params, force_grid_dimensions) == 880, "dims @880");
+_Static_assert(offsetof(orc_sim_params, delta_t) == 892, "delta_t @892");
+_Static_assert(offsetof(orc_sim_params, max_velocity) == 896, "max_velocity @896");
+_Static_assert(offsetof(orc_sim_params, bounding_volume_radius) == 900, "radius @900");
+_Static_assert(offsetof(orc_sim_params, cut_off_distance) == 904, "cutoff @904");
+_Static_assert(offsetof(orc_sim_params, distance_exponent) == 908, "exponent @908");
+_Static_assert(sizeof(orc_diagnostics) == 48, "diagnostics is 48 bytes");
+
+size_t orc_sizeof_particle(void) { return sizeof(orc_particle); }
+size_t orc_sizeof_sim_params(void) { return sizeof(orc_sim_params); }
+
+/* ---- src/sim_params.rs:20-31 ---- */
+void orc_sim_params_default(orc_sim_params* p)
+{
+    memset(p, 0, sizeof *p);
+    for (int i = 0; i < 5; ++i) p->particle_type_masses[i].mass = 1.0f;
+    p->force_grid_dimensions[0] = 10;
+    p->force_grid_dimensions[1] = 10;
+    p->force_grid_dimensions[2] = 10;
+    p->delta_t = 0.0f;
+    p->max_velocity = 100.0f;
+    p->bounding_volume_radius = 10.0f;
+    p->cut_off_distance = 1.0f;
+    p->distance_exponent = 0.0f;
+}
+
+/* ---- src/compute.wgsl:51-56 ---- */
+float orc_eval_poly7(float x, const float* coeffs)
+{
+    /* fields h,g,f,e,d,c,b,a are coeffs[0..8]: src/compute.wgsl:40-49 */
+    const float h = coeffs[0], g = coeffs[1], f = coeffs[2], e = coeffs[3];
+    const float d = coeffs[4], c = coeffs[5], b = coeffs[6], a = coeffs[7];
+    const float x2 = x * x;
+    const float x4 = x2 * x2;
+    const float x3 = x2 * x;
+    float r = (a * x4) * x3;
+    r = r + (b * x3) * x3;
+    r = r + (c * x2) * x3;
+    r = r + d * x4;
+    r = r + e * x3;
+    r = r + f * x2;
+    r = r + g * x;
+    r = r + h;
+    return r;
+}
+
+/* ---- src/compute.wgsl:58-66 ---- */
+float orc_wrap_symmetrically(float val, float max)
+{
+    if (val > max) return val - 2.0f * max;
+    if (val < -max) return val + 2.0f * max;
+    return val;
+}
+
+/* ---- src/compute.wgsl:68-79 ---- */
+float orc_map_range(float val, float start_a, float end_a, float start_b, float end_b)
+{
+    if (start_a == end_a) return start_b;
+    const float valc = fminf(fmaxf(val, start_a), end_a);
+    const float oz = (valc - start_a) / (end_a - start_a);
+    const float valb = oz * (end_b - start_b) + start_b;
+    return valb;
+}
+
+static uint32_t to_u32(float f)
+{
+    /* WGSL u32(f32) truncates; saturate outside the range so that the C
+     * conversion is never undefined. */
+    if (!(f >= 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+}
+
+/* ---- src/compute.wgsl:81-89 ---- */
+uint32_t orc_force_grid_index(float bounding_cube_side_length, const uint32_t* dims,
+                              const float* v)
+{
+    const float slh = bounding_cube_side_length * 0.5f;
+    const uint32_t ixx = to_u32(orc_map_range(v[0], -slh, slh, 0.0f, (float)dims[0]));
+    const uint32_t ixy = to_u32(orc_map_range(v[1], -slh, slh, 0.0f, (float)dims[1]));
+    const uint32_t ixz = to_u32(orc_map_range(v[2], -slh, slh, 0.0f, (float)dims[2]));
+    return ixx * dims[1] * dims[2] + ixy * dims[2] + ixz;
+}
+
+static uint32_t clamp_cell(uint32_t fgi, size_t n_cells)
+{
+    /* frozen out-of-bounds policy: clamp to the last cell */
+    if ((size_t)fgi >= n_cells) return (uint32_t)(n_cells - 1);
+    return fgi;
+}
+
+static float length3(const float* v)
+{
+    return sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+}
+
+/*
+ * The pair loop contributes exactly +0 when every coefficient of every
+ * polynomial is +-0 (finite inputs: dN*0*m*df = +-0 and +0 + +-0 = +0), or
+ * when no distance can pass both cut-offs (cut_off_distance < 0.001):
+ * src/compute.wgsl:126-131,139.
+ */
+int orc_pair_term_inert(const orc_sim_params* p)
+{
+    if (p->cut_off_distance < 0.001f) return 1;
+    for (int k = 0; k < 25; ++k)
+        for (int c = 0; c < 8; ++c)
+            if (p->attraction_force[k].coeffs[c] != 0.0f) return 0;
+    return 1;
+}
+
+/* ---- one invocation of src/compute.wgsl:97-181 for particle `index` ---- */
+static void step_one(const orc_sim_params* params, const orc_particle* src,
+                     orc_particle* dst, size_t total, size_t index,
+                     const float (*grid)[4], size_t n_cells, int skip_pairs, float decay)
+{
+    float vPos[3] = { src[index].pos[0], src[index].pos[1], src[index].pos[2] };
+    float vVel[3] = { src[index].vel[0], src[index].vel[1], src[index].vel[2] };
+    const uint32_t vParticleType = src[index].ty;
+    const float vMass = params->particle_type_masses[vParticleType].mass;
+    const float deltaT = params->delta_t;
+
+    float cAcc[3] = { 0.0f, 0.0f, 0.0f };
+
+    /* src/compute.wgsl:115-144; `continue` runs the continuing block, so i
+     * always advances. */
+    if (!skip_pairs) {
+        for (size_t i = 0; i < total; ++i) {
+            if (i == index) continue;
+            float direction[3] = { src[i].pos[0] - vPos[0], src[i].pos[1] - vPos[1],
+                                   src[i].pos[2] - vPos[2] };
+            const float direction_length = length3(direction);
+            if (direction_length < 0.001f) continue;
+            if (direction_length > params->cut_off_distance) continue;
+            const float distance_factor = powf(direction_length, params->distance_exponent);
+            const float len = length3(direction); /* normalize() recomputes the length */
+            const float directionN[3] = { direction[0] / len, direction[1] / len,
+                                          direction[2] / len };
+            const uint32_t attractionForceIndex = src[i].ty + vParticleType * 5u;
+            const float m2 = params->particle_type_masses[src[i].ty].mass;
+            const float pv = orc_eval_poly7(direction_length,
+                                            params->attraction_force[attractionForceIndex].coeffs);
+            for (int c = 0; c < 3; ++c) {
+                float t = directionN[c] * pv;
+                t = t * m2;
+                t = t * distance_factor;
+                cAcc[c] = cAcc[c] + t;
+            }
+        }
+    }
+
+    /* src/compute.wgsl:147-148 */
+    const uint32_t fgi = clamp_cell(
+        orc_force_grid_index(params->bounding_volume_radius * 2.0f,
+                             params->force_grid_dimensions, vPos),
+        n_cells);
+    for (int c = 0; c < 3; ++c) {
+        const float t = 10.0f * grid[fgi][c];
+        cAcc[c] = cAcc[c] + t / vMass;
+    }
+
+    /* src/compute.wgsl:151,154; decay = exp(-deltaT) is the same for every
+     * particle and is evaluated once per step by the callers. */
+    for (int c = 0; c < 3; ++c) vVel[c] = vVel[c] * decay;
+    for (int c = 0; c < 3; ++c) vVel[c] = vVel[c] + cAcc[c] * deltaT;
+
+    /* src/compute.wgsl:157-160 */
+    const float vel = length3(vVel);
+    if (vel > 0.001f) {
+        const float nlen = length3(vVel);
+        const float capped = fminf(fmaxf(vel, 0.0f), params->max_velocity);
+        for (int c = 0; c < 3; ++c) vVel[c] = (vVel[c] / nlen) * capped;
+    }
+
+    /* src/compute.wgsl:163 */
+    for (int c = 0; c < 3; ++c) vPos[c] = vPos[c] + vVel[c] * deltaT;
+
+    /* src/compute.wgsl:170-172 */
+    for (int c = 0; c < 3; ++c)
+        vPos[c] = orc_wrap_symmetrically(vPos[c], params->bounding_volume_radius);
+
+    /* src/compute.wgsl:180 */
+    orc_particle out;
+    out.pos[0] = vPos[0]; out.pos[1] = vPos[1]; out.pos[2] = vPos[2]; out.pos[3] = 1.0f;
+    out.vel[0] = vVel[0]; out.vel[1] = vVel[1]; out.vel[2] = vVel[2]; out.vel[3] = 1.0f;
+    out.ty = src[index].ty;
+    out.pad[0] = out.pad[1] = out.pad[2] = 0;
+    dst[index] = out;
+}
+
+/*
+ * Update particles [first, first+count) of a set of `total`.  `mode`:
+ * 0 = always run the pair loop, as the shader does;
+ * 1 = skip it when orc_pair_term_inert() proves it contributes nothing.
+ */
+void orc_step_range(const orc_sim_params* params, const orc_particle* src, orc_particle* dst,
+                    size_t total, size_t first, size_t count,
+                    const float (*grid)[4], size_t n_cells, int mode)
+{
+    const int skip = (mode == 1) && orc_pair_term_inert(params);
+    const float decay = expf(-params->delta_t);
+    for (size_t i = first; i < first + count; ++i)
+        step_one(params, src, dst, total, i, grid, n_cells, skip, decay);
+}
+
+/* Whole-set update, optionally split by index range over `threads` threads. */
+void orc_step(const orc_sim_params* params, const orc_particle* src, orc_particle* dst,
+              size_t total, const float (*grid)[4], size_t n_cells, int mode, int threads)
+{
+    const int skip = (mode == 1) && orc_pair_term_inert(params);
+    const float decay = expf(-params->delta_t);
+#ifdef _OPENMP
+    if (threads > 1) {
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (long long i = 0; i < (long long)total; ++i)
+            step_one(params, src, dst, total, (size_t)i, grid, n_cells, skip, decay);
+        return;
+    }
+#endif
+    (void)threads;
+    for (size_t i = 0; i < total; ++i)
+        step_one(params, src, dst, total, i, grid, n_cells, skip, decay);
+}
+
+/*
+ * `steps` updates with the reference's ping-pong (src/compute.rs:147-180,
+ * 221-227): step k reads buffer (k & 1) and writes the other.  Returns the
+ * index (0/1) of the buffer holding the latest state.
+ */
+int orc_run(const orc_sim_params* params, orc_particle* buf0, orc_particle* buf1,
+            size_t total, const float (*grid)[4], size_t n_cells,
+            int steps, int mode, int threads)
+{
+    orc_particle* bufs[2] = { buf0, buf1 };
+    int swap = 0;
+    for (int s = 0; s < steps; ++s) {
+        orc_step(params, bufs[swap], bufs[swap ^ 1], total, grid, n_cells, mode, threads);
+        swap ^= 1;
+    }
+    return swap;
+}
+
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* Flat cell index each particle would fetch: src/compute.wgsl:147. */
+void orc_cell_indices(const orc_sim_params* params, const orc_particle* particles, size_t n,
+                      size_t n_cells, uint32_t* out)
+{
+    for (size_t i = 0; i < n; ++i)
+        out[i] = clamp_cell(orc_force_grid_index(params->bounding_volume_radius * 2.0f,
+                                                 params->force_grid_dimensions,
+                                                 particles[i].pos),
+                            n_cells);
+}
+
+/* Diagnostics (not in the reference): count, sum 0.5*m*|v|^2 in f64, bounds. */
+void orc_diagnostics_of(const orc_sim_params* params, const orc_particle* particles, size_t n,
+                        orc_diagnostics* out)
+{
+    double ke = 0.0;
+    float mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    float nmn[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (size_t i = 0; i < n; ++i) {
+        const double m = (double)params->particle_type_masses[particles[i].ty].mass;
+        const double vx = particles[i].vel[0], vy = particles[i].vel[1], vz = particles[i].vel[2];
+        ke += 0.5 * m * ((vx * vx + vy * vy) + vz * vz);
+        for (int c = 0; c < 3; ++c) {
+            mx[c] = fmaxf(mx[c], particles[i].pos[c]);
+            nmn[c] = fmaxf(nmn[c], -particles[i].pos[c]);
+        }
+    }
+    memset(out, 0, sizeof *out);
+    out->count = (double)n;
+    out->kinetic_energy = ke;
+    for (int c = 0; c < 3; ++c) { out->pos_max[c] = mx[c]; out->neg_pos_min[c] = nmn[c]; }
+}
+
+/* ---- scene generators ---- */
+
+/* Lattice of src/main.rs:117-154: pos = (ix/nx*max.x, iy/ny*max.y, iz/nz*max.z, 1),
+ * vel = 0 (all four lanes), ty = flat index % 5. */
+void orc_lattice_particles(orc_particle* out, float max_x, float max_y, float max_z,
+                           size_t nx, size_t ny, size_t nz)
+{
+    for (size_t ix = 0; ix < nx; ++ix)
+        for (size_t iy = 0; iy < ny; ++iy)
+            for (size_t iz = 0; iz < nz; ++iz) {
+                const size_t index = ix * ny * nz + iy * nz + iz;
+                orc_particle p;
+                memset(&p, 0, sizeof p);
+                p.pos[0] = ((float)ix / (float)nx) * max_x;
+                p.pos[1] = ((float)iy / (float)ny) * max_y;
+                p.pos[2] = ((float)iz / (float)nz) * max_z;
+                p.pos[3] = 1.0f;
+                p.ty = (uint32_t)(index % 5);
+                out[index] = p;
+            }
+}
+
+/* Grid::new_centered + get_force_vectors: src/grid.rs:68-103.
+ * v = (nx,ny,nz)*0.5 - (ix,iy,iz), w = 1. */
+void orc_grid_centered(float (*out)[4], size_t nx, size_t ny, size_t nz)
+{
+    const float cx = (float)nx * 0.5f, cy = (float)ny * 0.5f, cz = (float)nz * 0.5f;
+    size_t k = 0;
+    for (size_t ix = 0; ix < nx; ++ix)
+        for (size_t iy = 0; iy < ny; ++iy)
+            for (size_t iz = 0; iz < nz; ++iz) {
+                out[k][0] = cx - (float)ix;
+                out[k][1] = cy - (float)iy;
+                out[k][2] = cz - (float)iz;
+                out[k][3] = 1.0f;
+                ++k;
+            }
+}
+
+/* Grid::get_positions: src/grid.rs:119-138 with bounds pos = -r, dir = 2r
+ * (src/sim_params.rs:33-45). */
+void orc_grid_positions(float (*out)[4], size_t nx, size_t ny, size_t nz, float radius)
+{
+    const float left = -radius, dir = 2.0f * radius;
+    size_t k = 0;
+    for (size_t ix = 0; ix < nx; ++ix)
+        for (size_t iy = 0; iy < ny; ++iy)
+            for (size_t iz = 0; iz < nz; ++iz) {
+                out[k][0] = left + dir * (((float)ix + 0.5f) / (float)nx);
+                out[k][1] = left + dir * (((float)iy + 0.5f) / (float)ny);
+                out[k][2] = left + dir * (((float)iz + 0.5f) / (float)nz);
+                out[k][3] = 1.0f;
+                ++k;
+            }
+}
+
+/* Counter-based hash for the seeded synthetic scene (splitmix64 finaliser).
+ * The reference's generator (src/main.rs:41-48,156-169) is unseeded thread
+ * RNG; only its distribution max*(u - 0.5), u in [0,1), is reproduced. */
+static uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+float orc_synth_uniform(uint64_t seed, uint64_t global_index, uint32_t axis)
+{
+    const uint64_t h = mix64(seed ^ mix64(global_index * 8ULL + (uint64_t)axis));
+    return (float)(h >> 40) * (1.0f / 16777216.0f); /* top 24 bits -> [0,1) */
+}
+
+void orc_synth_particles(orc_particle* out, size_t n, uint64_t seed, uint64_t first_global_index,
+                         float pos_extent, float vel_extent)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const uint64_t g = first_global_index + (uint64_t)i;
+        orc_particle p;
+        memset(&p, 0, sizeof p);
+        for (uint32_t c = 0; c < 3; ++c) {
+            p.pos[c] = pos_extent * (orc_synth_uniform(seed, g, c) - 0.5f);
+            p.vel[c] = vel_extent * (orc_synth_uniform(seed, g, 3u + c) - 0.5f);
+        }
+        p.pos[3] = 1.0f;
+        p.vel[3] = 1.0f;
+        p.ty = (uint32_t)(g % 5ULL);
+        out[i] = p;
+    }
+}

@@ -1,0 +1,17 @@
+"""MI355X-native particle update behind the reference's ``Compute`` surface.
+
+The compute backend is the in-tree HIP library ``libparticles_hip.so``
+(gfx950); see include/particles_hip.h for the C ABI.
+"""
+from .particle import PARTICLE_DTYPE, MASS_WRAP_DTYPE, NUM_TYPES, empty_particles, lattice_particles, random_particles
+from .poly7 import POLY7_DTYPE, Poly7
+from .grid import Bounds, Grid
+from .sim_params import SIM_PARAMS_DTYPE, SimParams
+from ._lib import PclError, KERNEL_NONE, KERNEL_STREAM, KERNEL_PAIRS
+from .compute import Compute
+
+__all__ = [
+    "PARTICLE_DTYPE", "MASS_WRAP_DTYPE", "NUM_TYPES", "empty_particles", "lattice_particles", "random_particles",
+    "POLY7_DTYPE", "Poly7", "Bounds", "Grid", "SIM_PARAMS_DTYPE", "SimParams",
+    "PclError", "KERNEL_NONE", "KERNEL_STREAM", "KERNEL_PAIRS", "Compute",
+]

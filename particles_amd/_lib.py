@@ -1,0 +1,103 @@
+"""ctypes binding of the C ABI declared in include/particles_hip.h.
+
+The HIP library is the only compute backend: when it is missing or cannot be
+loaded this module raises, there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libparticles_hip.so")
+
+PCL_OK = 0
+PCL_ERR_INVALID = -1
+PCL_ERR_HIP = -2
+PCL_ERR_NO_DEVICE = -3
+PCL_ERR_OUT_OF_RANGE = -4
+
+KERNEL_NONE, KERNEL_STREAM, KERNEL_PAIRS = 0, 1, 2
+
+
+class PclError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"particles_hip error {code}: {message}")
+        self.code = code
+
+
+class Diagnostics(C.Structure):
+    """pcl_diagnostics (48 bytes)."""
+    _fields_ = [
+        ("count", C.c_double),
+        ("kinetic_energy", C.c_double),
+        ("pos_max", C.c_float * 3),
+        ("neg_pos_min", C.c_float * 3),
+        ("pad", C.c_float * 2),
+    ]
+
+
+assert C.sizeof(Diagnostics) == 48
+
+_vp, _sz, _u64, _u32, _i, _f = C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_int, C.c_float
+
+# name -> (restype, argtypes); every symbol the header declares.
+SIGNATURES = {
+    "pcl_last_error": (C.c_char_p, []),
+    "pcl_device_count": (_i, []),
+    "pcl_sim_params_default": (None, [_vp]),
+    "pcl_create": (_i, [_vp, _sz, _vp, _sz, _i, C.POINTER(_vp)]),
+    "pcl_destroy": (_i, [_vp]),
+    "pcl_upload_particles": (_i, [_vp, _vp, _sz]),
+    "pcl_upload_particles_soa": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcl_generate_particles": (_i, [_vp, _sz, _u64, _u64, _f, _f]),
+    "pcl_update_force_grid": (_i, [_vp, _vp, _sz]),
+    "pcl_update_force_grid_device": (_i, [_vp, _vp, _sz]),
+    "pcl_patch_force_grid": (_i, [_vp, _sz, _vp, _sz]),
+    "pcl_patch_force_grid_device": (_i, [_vp, _sz, _vp, _sz]),
+    "pcl_update_sim_params": (_i, [_vp, _vp]),
+    "pcl_step": (_i, [_vp]),
+    "pcl_step_dt": (_i, [_vp, _f]),
+    "pcl_force_pair_kernel": (_i, [_vp, _i]),
+    "pcl_last_step_kernel": (_i, [_vp]),
+    "pcl_enable_step_diagnostics": (_i, [_vp, _i]),
+    "pcl_num_particles": (_sz, [_vp]),
+    "pcl_step_count": (_u64, [_vp]),
+    "pcl_read_particles": (_i, [_vp, _vp, _sz, _sz]),
+    "pcl_read_soa": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcl_pack_particles_device": (_i, [_vp, _vp, _sz, _sz]),
+    "pcl_diagnostics_read": (_i, [_vp, C.POINTER(Diagnostics)]),
+    "pcl_diagnostics_device": (_i, [_vp, _vp]),
+    "pcl_debug_cell_indices": (_i, [_vp, _vp, _sz, _sz]),
+    "pcl_set_stream": (_i, [_vp, _vp]),
+    "pcl_synchronize": (_i, [_vp]),
+    "pcl_timer_start": (_i, [_vp]),
+    "pcl_timer_stop": (_i, [_vp, C.POINTER(_f)]),
+    "pcl_launch_geometry": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "pcl_set_tuning": (_i, [_vp, _u32, _u32]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libparticles_hip.so (built in-tree by ``make``); raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make` at the repository root "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != PCL_OK:
+        msg = load().pcl_last_error()
+        raise PclError(code, msg.decode("utf-8", "replace") if msg else "")
+    return code

@@ -1,0 +1,204 @@
+"""Host-side mirror of the reference's ``Compute`` (src/compute.rs:11-228)
+over the gfx950 C ABI (include/particles_hip.h).
+
+Method names and argument meaning follow the reference: ``Compute.new``
+(compute.rs:25), ``upload_particles`` (:182), ``update_force_grid`` (:198),
+``update_sim_params`` (:206), ``compute`` (:221), ``num_particles`` (:19).
+The wgpu ``device``/``ComputePass`` arguments become the HIP device ordinal
+given at construction.  The reference has no error returns (wgpu validation
+failures panic); here invalid arguments raise ``PclError``.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .particle import PARTICLE_DTYPE
+from .sim_params import SIM_PARAMS_DTYPE, SimParams
+
+
+def _as_particles(particles):
+    a = np.ascontiguousarray(particles)
+    if a.dtype != PARTICLE_DTYPE:
+        raise TypeError("particles must be an array of PARTICLE_DTYPE records (48 bytes each)")
+    return a.reshape(-1)
+
+
+def _as_cells(force_grid):
+    a = np.ascontiguousarray(force_grid, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] != 4:
+        raise TypeError("force_grid must have shape (n_cells, 4): [x, y, z, 1.0] per cell")
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+class Compute:
+    """Owns the device copy of the particle state, field and parameters."""
+
+    def __init__(self, particles, force_grid, device=0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        p = _as_particles(particles)
+        g = _as_cells(force_grid)
+        _lib.check(self._lib.pcl_create(_ptr(p), p.shape[0], _ptr(g), g.shape[0], int(device), C.byref(self._h)))
+        self.device = int(device)
+
+    @classmethod
+    def new(cls, particles, force_grid, device=0):
+        """``Compute::new(device, particles, force_grid)`` (compute.rs:25):
+        copies both inputs; parameters start as ``SimParams::new()``
+        (delta_t = 0) until ``update_sim_params`` is called."""
+        return cls(particles, force_grid, device)
+
+    # -- lifetime -------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.pcl_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- the reference's surface ---------------------------------------
+    @property
+    def num_particles(self):
+        return int(self._lib.pcl_num_particles(self._h))
+
+    def upload_particles(self, particles):
+        p = _as_particles(particles)
+        _lib.check(self._lib.pcl_upload_particles(self._h, _ptr(p), p.shape[0]))
+
+    def update_force_grid(self, force_grid):
+        g = _as_cells(force_grid)
+        _lib.check(self._lib.pcl_update_force_grid(self._h, _ptr(g), g.shape[0]))
+
+    def update_sim_params(self, sim_params):
+        raw = sim_params.raw if isinstance(sim_params, SimParams) else np.asarray(sim_params)
+        if raw.dtype != SIM_PARAMS_DTYPE:
+            raise TypeError("sim_params must be a SimParams or a SIM_PARAMS_DTYPE record (912 bytes)")
+        raw = np.ascontiguousarray(raw)
+        _lib.check(self._lib.pcl_update_sim_params(self._h, raw.ctypes.data_as(C.c_void_p)))
+
+    def compute(self):
+        """One update src -> dst, then flip (compute.rs:221-227). Asynchronous."""
+        _lib.check(self._lib.pcl_step(self._h))
+
+    # -- north-star conveniences ---------------------------------------
+    def step(self, dt=None):
+        """``step(dt)``: set delta_t (when given) and run one update."""
+        if dt is None:
+            _lib.check(self._lib.pcl_step(self._h))
+        else:
+            _lib.check(self._lib.pcl_step_dt(self._h, float(dt)))
+
+    def patch_force_grid(self, first_cell, cells):
+        g = _as_cells(cells)
+        _lib.check(self._lib.pcl_patch_force_grid(self._h, int(first_cell), _ptr(g), g.shape[0]))
+
+    def update_force_grid_device(self, dev_ptr, n_cells):
+        _lib.check(self._lib.pcl_update_force_grid_device(self._h, C.c_void_p(int(dev_ptr)), int(n_cells)))
+
+    def patch_force_grid_device(self, first_cell, dev_ptr, count):
+        _lib.check(self._lib.pcl_patch_force_grid_device(self._h, int(first_cell), C.c_void_p(int(dev_ptr)), int(count)))
+
+    def upload_particles_soa(self, x, y, z, vx, vy, vz, ty):
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (x, y, z, vx, vy, vz)]
+        t = np.ascontiguousarray(ty, dtype=np.uint8)
+        n = t.shape[0]
+        if any(a.shape != (n,) for a in arrs):
+            raise ValueError("all SoA arrays must have the same length")
+        _lib.check(self._lib.pcl_upload_particles_soa(self._h, n, *[_ptr(a) for a in arrs], _ptr(t)))
+
+    def generate_particles(self, n, seed, first_global_index=0, pos_extent=2.0, vel_extent=10.0):
+        _lib.check(self._lib.pcl_generate_particles(self._h, int(n), int(seed), int(first_global_index),
+                                                    float(pos_extent), float(vel_extent)))
+
+    def read_particles(self, first=0, count=None):
+        """AoS records of the latest state (pos.w = vel.w = 1.0)."""
+        if count is None:
+            count = self.num_particles - first
+        out = np.zeros(int(count), dtype=PARTICLE_DTYPE)
+        _lib.check(self._lib.pcl_read_particles(self._h, _ptr(out), int(first), int(count)))
+        return out
+
+    def read_soa(self, first=0, count=None):
+        if count is None:
+            count = self.num_particles - first
+        count = int(count)
+        arrs = [np.zeros(count, dtype=np.float32) for _ in range(6)]
+        ty = np.zeros(count, dtype=np.uint8)
+        _lib.check(self._lib.pcl_read_soa(self._h, int(first), count, *[_ptr(a) for a in arrs], _ptr(ty)))
+        return dict(zip(("x", "y", "z", "vx", "vy", "vz"), arrs), ty=ty)
+
+    def pack_particles_device(self, dev_ptr, first=0, count=None):
+        if count is None:
+            count = self.num_particles - first
+        _lib.check(self._lib.pcl_pack_particles_device(self._h, C.c_void_p(int(dev_ptr)), int(first), int(count)))
+
+    def diagnostics(self):
+        d = _lib.Diagnostics()
+        _lib.check(self._lib.pcl_diagnostics_read(self._h, C.byref(d)))
+        return {
+            "count": int(d.count),
+            "kinetic_energy": float(d.kinetic_energy),
+            "pos_max": np.array(d.pos_max[:], dtype=np.float32),
+            "pos_min": -np.array(d.neg_pos_min[:], dtype=np.float32),
+        }
+
+    def diagnostics_device(self, dev_ptr):
+        _lib.check(self._lib.pcl_diagnostics_device(self._h, C.c_void_p(int(dev_ptr))))
+
+    def enable_step_diagnostics(self, enable=True):
+        _lib.check(self._lib.pcl_enable_step_diagnostics(self._h, int(bool(enable))))
+
+    def debug_cell_indices(self, first=0, count=None):
+        if count is None:
+            count = self.num_particles - first
+        out = np.zeros(int(count), dtype=np.uint32)
+        _lib.check(self._lib.pcl_debug_cell_indices(self._h, _ptr(out), int(first), int(count)))
+        return out
+
+    def force_pair_kernel(self, enable=True):
+        _lib.check(self._lib.pcl_force_pair_kernel(self._h, int(bool(enable))))
+
+    @property
+    def last_step_kernel(self):
+        return int(self._lib.pcl_last_step_kernel(self._h))
+
+    @property
+    def step_count(self):
+        return int(self._lib.pcl_step_count(self._h))
+
+    def set_stream(self, hip_stream):
+        _lib.check(self._lib.pcl_set_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else 0)))
+
+    def synchronize(self):
+        _lib.check(self._lib.pcl_synchronize(self._h))
+
+    def timer_start(self):
+        _lib.check(self._lib.pcl_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _lib.check(self._lib.pcl_timer_stop(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def launch_geometry(self):
+        g, b, p = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _lib.check(self._lib.pcl_launch_geometry(self._h, C.byref(g), C.byref(b), C.byref(p)))
+        return {"grid_blocks": g.value, "block_threads": b.value, "particles_per_lane": p.value}
+
+    def set_tuning(self, grid_blocks=0, variant=0):
+        _lib.check(self._lib.pcl_set_tuning(self._h, int(grid_blocks), int(variant)))

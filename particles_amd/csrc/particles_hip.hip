@@ -1,0 +1,736 @@
+// particles_hip.hip — C ABI of the gfx950 particle-update library
+// (declarations and reference citations: include/particles_hip.h).
+//
+// One handle = one GPU.  Device memory per handle:
+//   state[2][6]  ping-pong fp32 arrays x,y,z,vx,vy,vz   (2 * 24 B per particle)
+//   ty           one byte per particle, never rewritten  (1 B per particle)
+//   field        float4 per cell
+// The step reads state[cur] and writes state[cur ^ 1], then flips `cur`
+// (reference ping-pong: src/compute.rs:147-180,221-227).
+#include "step_kernels.hpp"
+
+#include "particles_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+static_assert(sizeof(pcl_particle) == 48, "Particle is 48 bytes (src/main.rs:76-83)");
+static_assert(offsetof(pcl_particle, vel) == 16 && offsetof(pcl_particle, ty) == 32, "Particle offsets");
+static_assert(sizeof(pcl_poly7) == 32, "Poly7 is 32 bytes (src/poly7.rs:6-10)");
+static_assert(sizeof(pcl_mass_wrap) == 16, "MassWrap is 16 bytes (src/main.rs:196-201)");
+static_assert(sizeof(pcl_sim_params) == 912, "SimParams is 912 bytes (src/sim_params.rs:6-17)");
+static_assert(offsetof(pcl_sim_params, particle_type_masses) == 800, "masses @800");
+static_assert(offsetof(pcl_sim_params, force_grid_dimensions) == 880, "dims @880");
+static_assert(offsetof(pcl_sim_params, delta_t) == 892, "delta_t @892");
+static_assert(offsetof(pcl_sim_params, max_velocity) == 896, "max_velocity @896");
+static_assert(offsetof(pcl_sim_params, bounding_volume_radius) == 900, "radius @900");
+static_assert(offsetof(pcl_sim_params, cut_off_distance) == 904, "cut_off @904");
+static_assert(offsetof(pcl_sim_params, distance_exponent) == 908, "exponent @908");
+static_assert(sizeof(pcl_diagnostics) == 48 && sizeof(pcl::DiagOut) == 48, "diagnostics is 48 bytes");
+static_assert(sizeof(pcl::ParamsBlock) == sizeof(pcl_sim_params), "device view of SimParams");
+static_assert(sizeof(pcl::ParticleAoS) == sizeof(pcl_particle), "device view of Particle");
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define PCL_HIP_TRY(expr)                                                              \
+    do {                                                                               \
+        hipError_t pcl_e_ = (expr);                                                    \
+        if (pcl_e_ != hipSuccess)                                                      \
+            return fail(PCL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(pcl_e_)); \
+    } while (0)
+
+#define PCL_REQUIRE(cond, msg)                       \
+    do {                                             \
+        if (!(cond)) return fail(PCL_ERR_INVALID, msg); \
+    } while (0)
+
+constexpr size_t kStagingRecords = size_t(1) << 22;  // AoS staging chunk: 4 Mi records = 192 MiB
+constexpr uint32_t kLdsFieldMaxBytes = 64u * 1024u;  // fields up to this size are staged in LDS
+
+}  // namespace
+
+struct pcl_compute {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+
+    size_t n = 0;
+    size_t capacity = 0;
+    float* state[2][6] = {{nullptr}};
+    uint8_t* ty = nullptr;
+    int cur = 0;
+    uint64_t steps = 0;
+
+    pcl::f32x4* field = nullptr;
+    size_t n_cells = 0;
+    size_t field_capacity = 0;
+
+    pcl_sim_params params;
+    pcl_sim_params* d_params = nullptr;
+    bool params_dirty = true;
+
+    bool force_pairs = false;
+    bool step_diag = false;
+    bool diag_current = false;  // d_diag describes state[cur]
+    int last_kernel = PCL_KERNEL_NONE;
+
+    pcl::DiagPartial* d_partials = nullptr;
+    size_t partials_capacity = 0;
+    pcl::DiagOut* d_diag = nullptr;
+
+    uint32_t grid_cap = 0;  // 0: default
+    uint32_t variant = 0;
+};
+
+namespace {
+
+int bind(const pcl_compute* h)
+{
+    if (!h) return fail(PCL_ERR_INVALID, "null handle");
+    PCL_HIP_TRY(hipSetDevice(h->device));
+    return PCL_OK;
+}
+
+void free_particles(pcl_compute* h)
+{
+    for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 6; ++a) {
+            if (h->state[b][a]) (void)hipFree(h->state[b][a]);
+            h->state[b][a] = nullptr;
+        }
+    if (h->ty) (void)hipFree(h->ty);
+    h->ty = nullptr;
+    h->capacity = 0;
+}
+
+int reserve_particles(pcl_compute* h, size_t n)
+{
+    if (n <= h->capacity) return PCL_OK;
+    // All work queued on the old arrays must finish before they are freed.
+    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+    free_particles(h);
+    for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 6; ++a) PCL_HIP_TRY(hipMalloc((void**)&h->state[b][a], n * sizeof(float)));
+    PCL_HIP_TRY(hipMalloc((void**)&h->ty, n));
+    h->capacity = n;
+    return PCL_OK;
+}
+
+int reserve_field(pcl_compute* h, size_t n_cells)
+{
+    if (n_cells <= h->field_capacity) return PCL_OK;
+    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->field) (void)hipFree(h->field);
+    h->field = nullptr;
+    h->field_capacity = 0;
+    PCL_HIP_TRY(hipMalloc((void**)&h->field, n_cells * sizeof(pcl::f32x4)));
+    h->field_capacity = n_cells;
+    return PCL_OK;
+}
+
+int reserve_partials(pcl_compute* h, size_t blocks)
+{
+    if (blocks <= h->partials_capacity) return PCL_OK;
+    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->d_partials) (void)hipFree(h->d_partials);
+    h->d_partials = nullptr;
+    h->partials_capacity = 0;
+    const size_t cap = std::max<size_t>(blocks, 4096);
+    PCL_HIP_TRY(hipMalloc((void**)&h->d_partials, cap * sizeof(pcl::DiagPartial)));
+    h->partials_capacity = cap;
+    return PCL_OK;
+}
+
+pcl::StateSoA soa_of(const pcl_compute* h, int which)
+{
+    pcl::StateSoA s;
+    for (int a = 0; a < 6; ++a) s.a[a] = h->state[which][a];
+    return s;
+}
+
+// The launch-uniform operands of src/compute.wgsl, each evaluated once with
+// the same fp32 operation the shader applies per invocation.
+pcl::StepUniforms uniforms_of(const pcl_compute* h)
+{
+    const pcl_sim_params& p = h->params;
+    pcl::StepUniforms U;
+    U.decay = expf(-p.delta_t);                                 // wgsl:151
+    U.dt = p.delta_t;
+    U.max_velocity = p.max_velocity;
+    U.radius = p.bounding_volume_radius;
+    U.two_radius = 2.0f * p.bounding_volume_radius;             // wgsl:60,63
+    const float side = p.bounding_volume_radius * 2.0f;         // wgsl:147
+    U.slh = side * 0.5f;                                        // wgsl:83
+    U.neg_slh = -U.slh;
+    U.span_a = U.slh - U.neg_slh;                               // wgsl:75
+    for (int c = 0; c < 3; ++c) U.span_b[c] = (float)p.force_grid_dimensions[c] - 0.0f;  // wgsl:77
+    U.dim_y = p.force_grid_dimensions[1];
+    U.dim_z = p.force_grid_dimensions[2];
+    U.last_cell = (uint32_t)(h->n_cells - 1);
+    U.degenerate = (U.neg_slh == U.slh) ? 1u : 0u;              // wgsl:69
+    for (int k = 0; k < 5; ++k) U.mass[k] = p.particle_type_masses[k].mass;
+    return U;
+}
+
+// The pair loop adds exactly +0 to the acceleration when every polynomial
+// coefficient is +-0, or when no distance can pass both cut-offs
+// (src/compute.wgsl:126-131,139); finite inputs assumed.
+bool pair_term_inert(const pcl_sim_params& p)
+{
+    if (p.cut_off_distance < 0.001f) return true;
+    for (int k = 0; k < PCL_NUM_POLYS; ++k)
+        for (int c = 0; c < 8; ++c)
+            if (p.attraction_force[k].coeffs[c] != 0.0f) return false;
+    return true;
+}
+
+uint32_t default_grid_cap(const pcl_compute* h)
+{
+    return h->grid_cap ? h->grid_cap : (uint32_t)h->num_cus * 8u;
+}
+
+uint32_t stream_grid(const pcl_compute* h, size_t n)
+{
+    const size_t groups = n / 4;
+    const size_t blocks = (groups + pcl::kBlockThreads - 1) / pcl::kBlockThreads;
+    return (uint32_t)std::max<size_t>(1, std::min<size_t>(blocks, default_grid_cap(h)));
+}
+
+uint32_t linear_grid(const pcl_compute* h, size_t count)
+{
+    const size_t blocks = (count + pcl::kBlockThreads - 1) / pcl::kBlockThreads;
+    return (uint32_t)std::max<size_t>(1, std::min<size_t>(blocks, (size_t)h->num_cus * 16u));
+}
+
+int launch_finalize(pcl_compute* h, uint32_t n_partials, pcl::DiagOut* dev_out)
+{
+    hipLaunchKernelGGL(pcl::diag_finalize_kernel, dim3(1), dim3(pcl::kBlockThreads), 0, h->stream,
+                       h->d_partials, n_partials, dev_out);
+    PCL_HIP_TRY(hipGetLastError());
+    return PCL_OK;
+}
+
+template <bool DIAG, bool NT>
+int launch_stream(pcl_compute* h, const pcl::StreamArgs& a, const pcl::StepUniforms& U, uint32_t grid,
+                  bool lds)
+{
+    if (lds) {
+        const size_t bytes = (size_t)a.lds_cells * sizeof(pcl::f32x4);
+        hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, true>), dim3(grid),
+                           dim3(pcl::kBlockThreads), bytes, h->stream, a, U);
+    } else {
+        hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, false>), dim3(grid),
+                           dim3(pcl::kBlockThreads), 0, h->stream, a, U);
+    }
+    PCL_HIP_TRY(hipGetLastError());
+    return PCL_OK;
+}
+
+int do_step(pcl_compute* h)
+{
+    if (int rc = bind(h)) return rc;
+    const bool inert = pair_term_inert(h->params);
+    const bool use_pairs = h->force_pairs || !inert;
+    h->last_kernel = use_pairs ? PCL_KERNEL_PAIRS : PCL_KERNEL_STREAM;
+    if (h->n == 0) {
+        h->cur ^= 1;
+        h->steps += 1;
+        h->diag_current = false;
+        return PCL_OK;
+    }
+    PCL_REQUIRE(h->n_cells >= 1, "the force grid is empty");
+    const pcl::StepUniforms U = uniforms_of(h);
+    const int src = h->cur, dst = h->cur ^ 1;
+    uint32_t grid = 0;
+
+    if (!use_pairs) {
+        grid = stream_grid(h, h->n);
+        if (h->step_diag)
+            if (int rc = reserve_partials(h, grid)) return rc;
+        pcl::StreamArgs a;
+        for (int k = 0; k < 6; ++k) { a.src[k] = h->state[src][k]; a.dst[k] = h->state[dst][k]; }
+        a.ty = h->ty;
+        a.field = h->field;
+        a.n = h->n;
+        a.partials = h->d_partials;
+        // Stage the field in LDS when it is small and every persistent block
+        // amortises the copy over at least a few tiles.
+        const size_t field_bytes = h->n_cells * sizeof(pcl::f32x4);
+        const bool lds = field_bytes <= kLdsFieldMaxBytes && (h->variant & 2u) == 0 &&
+                         h->n >= (size_t)grid * pcl::kTileParticles * 4;
+        a.lds_cells = lds ? (uint32_t)h->n_cells : 0u;
+        const bool nt = (h->variant & 1u) == 0;
+        int rc;
+        if (h->step_diag) rc = nt ? launch_stream<true, true>(h, a, U, grid, lds) : launch_stream<true, false>(h, a, U, grid, lds);
+        else              rc = nt ? launch_stream<false, true>(h, a, U, grid, lds) : launch_stream<false, false>(h, a, U, grid, lds);
+        if (rc) return rc;
+    } else {
+        if (h->params_dirty) {
+            PCL_HIP_TRY(hipMemcpyAsync(h->d_params, &h->params, sizeof(pcl_sim_params),
+                                       hipMemcpyHostToDevice, h->stream));
+            // The source is a member of the handle; wait so later edits cannot race the copy.
+            PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+            h->params_dirty = false;
+        }
+        const size_t blocks = (h->n + pcl::kBlockThreads - 1) / pcl::kBlockThreads;
+        PCL_REQUIRE(blocks <= 0x7FFFFFFFu, "too many particles for the pair kernel");
+        grid = (uint32_t)blocks;
+        if (h->step_diag)
+            if (int rc = reserve_partials(h, grid)) return rc;
+        pcl::PairArgs a;
+        for (int k = 0; k < 6; ++k) { a.src[k] = h->state[src][k]; a.dst[k] = h->state[dst][k]; }
+        a.ty = h->ty;
+        a.field = h->field;
+        a.params = reinterpret_cast<const pcl::ParamsBlock*>(h->d_params);
+        a.n = h->n;
+        a.partials = h->d_partials;
+        if (h->step_diag)
+            hipLaunchKernelGGL((pcl::step_pairs_kernel<true>), dim3(grid), dim3(pcl::kBlockThreads), 0,
+                               h->stream, a, U);
+        else
+            hipLaunchKernelGGL((pcl::step_pairs_kernel<false>), dim3(grid), dim3(pcl::kBlockThreads), 0,
+                               h->stream, a, U);
+        PCL_HIP_TRY(hipGetLastError());
+    }
+
+    h->cur = dst;
+    h->steps += 1;
+    if (h->step_diag) {
+        if (int rc = launch_finalize(h, grid, h->d_diag)) return rc;
+        h->diag_current = true;
+    } else {
+        h->diag_current = false;
+    }
+    return PCL_OK;
+}
+
+// Reduce diagnostics of state[cur] into h->d_diag unless already current.
+int ensure_diag(pcl_compute* h)
+{
+    if (h->diag_current) return PCL_OK;
+    const uint32_t grid = h->n ? linear_grid(h, h->n) : 1u;
+    if (int rc = reserve_partials(h, grid)) return rc;
+    hipLaunchKernelGGL(pcl::diag_reduce_kernel, dim3(grid), dim3(pcl::kBlockThreads), 0, h->stream,
+                       soa_of(h, h->cur), h->ty, (unsigned long long)h->n, uniforms_of(h), h->d_partials);
+    PCL_HIP_TRY(hipGetLastError());
+    if (int rc = launch_finalize(h, grid, h->d_diag)) return rc;
+    h->diag_current = true;
+    return PCL_OK;
+}
+
+int check_range(size_t first, size_t count, size_t n, const char* what)
+{
+    if (first > n || count > n - first)
+        return fail(PCL_ERR_OUT_OF_RANGE, std::string(what) + ": range outside [0, n)");
+    return PCL_OK;
+}
+
+int upload_field(pcl_compute* h, size_t first_cell, const void* src, size_t count, bool from_device)
+{
+    if (count == 0) return PCL_OK;
+    PCL_HIP_TRY(hipMemcpyAsync(h->field + first_cell, src, count * sizeof(pcl::f32x4),
+                               from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                               h->stream));
+    if (!from_device) PCL_HIP_TRY(hipStreamSynchronize(h->stream));  // caller's buffer is only valid during the call
+    return PCL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pcl_last_error(void) { return g_last_error.c_str(); }
+
+int pcl_device_count(void)
+{
+    int n = 0;
+    PCL_HIP_TRY(hipGetDeviceCount(&n));
+    return n;
+}
+
+void pcl_sim_params_default(pcl_sim_params* out)
+{
+    if (!out) return;
+    std::memset(out, 0, sizeof *out);
+    for (int k = 0; k < PCL_NUM_TYPES; ++k) out->particle_type_masses[k].mass = 1.0f;
+    out->force_grid_dimensions[0] = out->force_grid_dimensions[1] = out->force_grid_dimensions[2] = 10;
+    out->delta_t = 0.0f;
+    out->max_velocity = 100.0f;
+    out->bounding_volume_radius = 10.0f;
+    out->cut_off_distance = 1.0f;
+    out->distance_exponent = 0.0f;
+}
+
+int pcl_destroy(pcl_compute* h)
+{
+    if (!h) return PCL_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->own_stream && h->own_stream != h->stream) (void)hipStreamSynchronize(h->own_stream);
+    free_particles(h);
+    if (h->field) (void)hipFree(h->field);
+    if (h->d_params) (void)hipFree(h->d_params);
+    if (h->d_partials) (void)hipFree(h->d_partials);
+    if (h->d_diag) (void)hipFree(h->d_diag);
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return PCL_OK;
+}
+
+int pcl_create(const pcl_particle* particles, size_t n, const float (*force_grid)[4], size_t n_cells,
+               int device, pcl_compute** out)
+{
+    PCL_REQUIRE(out != nullptr, "pcl_create: out is null");
+    *out = nullptr;
+    PCL_REQUIRE(n == 0 || particles != nullptr, "pcl_create: particles is null");
+    PCL_REQUIRE(force_grid != nullptr && n_cells >= 1, "pcl_create: the force grid is empty");
+    PCL_REQUIRE(n_cells <= 0xFFFFFFFFull, "pcl_create: the force grid has more than 2^32 - 1 cells");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(PCL_ERR_NO_DEVICE, "pcl_create: no HIP device is visible");
+    PCL_REQUIRE(device >= 0 && device < count, "pcl_create: device ordinal out of range");
+    PCL_HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    PCL_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PCL_ERR_NO_DEVICE, std::string("pcl_create: device is ") + prop.gcnArchName +
+                                           ", this library is built for gfx950 only");
+
+    pcl_compute* h = new (std::nothrow) pcl_compute();
+    if (!h) return fail(PCL_ERR_INVALID, "pcl_create: out of host memory");
+    h->device = device;
+    h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    pcl_sim_params_default(&h->params);  // src/compute.rs:33: parameters start as SimParams::new()
+
+    auto cleanup = [&](int rc) { pcl_destroy(h); return rc; };
+#define PCL_CREATE_TRY(expr)                                                                    \
+    do {                                                                                        \
+        hipError_t pcl_e_ = (expr);                                                             \
+        if (pcl_e_ != hipSuccess)                                                               \
+            return cleanup(fail(PCL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(pcl_e_))); \
+    } while (0)
+    PCL_CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    PCL_CREATE_TRY(hipEventCreate(&h->ev_start));
+    PCL_CREATE_TRY(hipEventCreate(&h->ev_stop));
+    PCL_CREATE_TRY(hipMalloc((void**)&h->d_params, sizeof(pcl_sim_params)));
+    PCL_CREATE_TRY(hipMalloc((void**)&h->d_diag, sizeof(pcl::DiagOut)));
+#undef PCL_CREATE_TRY
+    if (int rc = reserve_partials(h, 1)) return cleanup(rc);
+    if (int rc = pcl_update_force_grid(h, force_grid, n_cells)) return cleanup(rc);
+    if (int rc = pcl_upload_particles(h, particles, n)) return cleanup(rc);
+    *out = h;
+    return PCL_OK;
+}
+
+int pcl_upload_particles(pcl_compute* h, const pcl_particle* particles, size_t n)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_REQUIRE(n == 0 || particles != nullptr, "pcl_upload_particles: particles is null");
+    for (size_t i = 0; i < n; ++i)
+        if (particles[i].ty >= PCL_NUM_TYPES)
+            return fail(PCL_ERR_INVALID, "pcl_upload_particles: particle " + std::to_string(i) +
+                                             " has type " + std::to_string(particles[i].ty) + " (must be < 5)");
+    if (int rc = reserve_particles(h, n)) return rc;
+    h->n = n;
+    h->diag_current = false;
+    if (n == 0) return PCL_OK;
+
+    const size_t chunk = std::min(n, kStagingRecords);
+    pcl::ParticleAoS* staging = nullptr;
+    PCL_HIP_TRY(hipMalloc((void**)&staging, chunk * sizeof(pcl::ParticleAoS)));
+    int rc = PCL_OK;
+    for (size_t first = 0; first < n && rc == PCL_OK; first += chunk) {
+        const size_t cnt = std::min(chunk, n - first);
+        hipError_t e = hipMemcpyAsync(staging, particles + first, cnt * sizeof(pcl_particle),
+                                      hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(pcl::unpack_aos_kernel, dim3(linear_grid(h, cnt)), dim3(pcl::kBlockThreads),
+                               0, h->stream, staging, (unsigned long long)cnt, soa_of(h, h->cur), h->ty,
+                               (unsigned long long)first);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(PCL_ERR_HIP, std::string("pcl_upload_particles: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(staging);
+    return rc;
+}
+
+int pcl_upload_particles_soa(pcl_compute* h, size_t n, const float* x, const float* y, const float* z,
+                             const float* vx, const float* vy, const float* vz, const uint8_t* ty)
+{
+    if (int rc = bind(h)) return rc;
+    const float* src[6] = {x, y, z, vx, vy, vz};
+    if (n) {
+        for (int a = 0; a < 6; ++a) PCL_REQUIRE(src[a] != nullptr, "pcl_upload_particles_soa: null array");
+        PCL_REQUIRE(ty != nullptr, "pcl_upload_particles_soa: ty is null");
+        for (size_t i = 0; i < n; ++i)
+            if (ty[i] >= PCL_NUM_TYPES)
+                return fail(PCL_ERR_INVALID, "pcl_upload_particles_soa: particle " + std::to_string(i) +
+                                                 " has type " + std::to_string(ty[i]) + " (must be < 5)");
+    }
+    if (int rc = reserve_particles(h, n)) return rc;
+    h->n = n;
+    h->diag_current = false;
+    if (n == 0) return PCL_OK;
+    for (int a = 0; a < 6; ++a)
+        PCL_HIP_TRY(hipMemcpyAsync(h->state[h->cur][a], src[a], n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    PCL_HIP_TRY(hipMemcpyAsync(h->ty, ty, n, hipMemcpyHostToDevice, h->stream));
+    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+    return PCL_OK;
+}
+
+int pcl_generate_particles(pcl_compute* h, size_t n, uint64_t seed, uint64_t first_global_index,
+                           float pos_extent, float vel_extent)
+{
+    if (int rc = bind(h)) return rc;
+    if (int rc = reserve_particles(h, n)) return rc;
+    h->n = n;
+    h->diag_current = false;
+    if (n == 0) return PCL_OK;
+    hipLaunchKernelGGL(pcl::generate_kernel, dim3(linear_grid(h, n)), dim3(pcl::kBlockThreads), 0, h->stream,
+                       soa_of(h, h->cur), h->ty, (unsigned long long)n, (unsigned long long)seed,
+                       (unsigned long long)first_global_index, pos_extent, vel_extent);
+    PCL_HIP_TRY(hipGetLastError());
+    return PCL_OK;
+}
+
+int pcl_update_force_grid(pcl_compute* h, const float (*force_grid)[4], size_t n_cells)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_REQUIRE(force_grid != nullptr && n_cells >= 1, "pcl_update_force_grid: the force grid is empty");
+    PCL_REQUIRE(n_cells <= 0xFFFFFFFFull, "pcl_update_force_grid: more than 2^32 - 1 cells");
+    if (int rc = reserve_field(h, n_cells)) return rc;
+    h->n_cells = n_cells;
+    return upload_field(h, 0, force_grid, n_cells, false);
+}
+
+int pcl_update_force_grid_device(pcl_compute* h, const void* dev_force_grid, size_t n_cells)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_REQUIRE(dev_force_grid != nullptr && n_cells >= 1, "pcl_update_force_grid_device: the force grid is empty");
+    PCL_REQUIRE(n_cells <= 0xFFFFFFFFull, "pcl_update_force_grid_device: more than 2^32 - 1 cells");
+    if (int rc = reserve_field(h, n_cells)) return rc;
+    h->n_cells = n_cells;
+    return upload_field(h, 0, dev_force_grid, n_cells, true);
+}
+
+int pcl_patch_force_grid(pcl_compute* h, size_t first_cell, const float (*cells)[4], size_t count)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_REQUIRE(count == 0 || cells != nullptr, "pcl_patch_force_grid: cells is null");
+    if (int rc = check_range(first_cell, count, h->n_cells, "pcl_patch_force_grid")) return rc;
+    return upload_field(h, first_cell, cells, count, false);
+}
+
+int pcl_patch_force_grid_device(pcl_compute* h, size_t first_cell, const void* dev_cells, size_t count)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_REQUIRE(count == 0 || dev_cells != nullptr, "pcl_patch_force_grid_device: dev_cells is null");
+    if (int rc = check_range(first_cell, count, h->n_cells, "pcl_patch_force_grid_device")) return rc;
+    return upload_field(h, first_cell, dev_cells, count, true);
+}
+
+int pcl_update_sim_params(pcl_compute* h, const pcl_sim_params* params)
+{
+    if (!h) return fail(PCL_ERR_INVALID, "null handle");
+    PCL_REQUIRE(params != nullptr, "pcl_update_sim_params: params is null");
+    h->params = *params;
+    h->params_dirty = true;
+    h->diag_current = false;  // the masses weight the kinetic energy
+    return PCL_OK;
+}
+
+int pcl_step(pcl_compute* h) { return do_step(h); }
+
+int pcl_step_dt(pcl_compute* h, float delta_t)
+{
+    if (!h) return fail(PCL_ERR_INVALID, "null handle");
+    h->params.delta_t = delta_t;
+    h->params_dirty = true;
+    return do_step(h);
+}
+
+int pcl_force_pair_kernel(pcl_compute* h, int enable)
+{
+    if (!h) return fail(PCL_ERR_INVALID, "null handle");
+    h->force_pairs = enable != 0;
+    return PCL_OK;
+}
+
+int pcl_last_step_kernel(const pcl_compute* h) { return h ? h->last_kernel : PCL_KERNEL_NONE; }
+
+int pcl_enable_step_diagnostics(pcl_compute* h, int enable)
+{
+    if (!h) return fail(PCL_ERR_INVALID, "null handle");
+    h->step_diag = enable != 0;
+    return PCL_OK;
+}
+
+size_t pcl_num_particles(const pcl_compute* h) { return h ? h->n : 0; }
+
+uint64_t pcl_step_count(const pcl_compute* h) { return h ? h->steps : 0; }
+
+int pcl_read_particles(pcl_compute* h, pcl_particle* out, size_t first, size_t count)
+{
+    if (int rc = bind(h)) return rc;
+    if (int rc = check_range(first, count, h->n, "pcl_read_particles")) return rc;
+    if (count == 0) return PCL_OK;
+    PCL_REQUIRE(out != nullptr, "pcl_read_particles: out is null");
+    const size_t chunk = std::min(count, kStagingRecords);
+    pcl::ParticleAoS* staging = nullptr;
+    PCL_HIP_TRY(hipMalloc((void**)&staging, chunk * sizeof(pcl::ParticleAoS)));
+    int rc = PCL_OK;
+    for (size_t done = 0; done < count && rc == PCL_OK; done += chunk) {
+        const size_t cnt = std::min(chunk, count - done);
+        hipLaunchKernelGGL(pcl::pack_aos_kernel, dim3(linear_grid(h, cnt)), dim3(pcl::kBlockThreads), 0,
+                           h->stream, soa_of(h, h->cur), h->ty, (unsigned long long)(first + done),
+                           (unsigned long long)cnt, staging);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(out + done, staging, cnt * sizeof(pcl_particle), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(PCL_ERR_HIP, std::string("pcl_read_particles: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(staging);
+    return rc;
+}
+
+int pcl_read_soa(pcl_compute* h, size_t first, size_t count, float* x, float* y, float* z, float* vx,
+                 float* vy, float* vz, uint8_t* ty)
+{
+    if (int rc = bind(h)) return rc;
+    if (int rc = check_range(first, count, h->n, "pcl_read_soa")) return rc;
+    if (count == 0) return PCL_OK;
+    float* dst[6] = {x, y, z, vx, vy, vz};
+    for (int a = 0; a < 6; ++a)
+        if (dst[a])
+            PCL_HIP_TRY(hipMemcpyAsync(dst[a], h->state[h->cur][a] + first, count * sizeof(float),
+                                       hipMemcpyDeviceToHost, h->stream));
+    if (ty) PCL_HIP_TRY(hipMemcpyAsync(ty, h->ty + first, count, hipMemcpyDeviceToHost, h->stream));
+    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+    return PCL_OK;
+}
+
+int pcl_pack_particles_device(pcl_compute* h, void* dev_out, size_t first, size_t count)
+{
+    if (int rc = bind(h)) return rc;
+    if (int rc = check_range(first, count, h->n, "pcl_pack_particles_device")) return rc;
+    if (count == 0) return PCL_OK;
+    PCL_REQUIRE(dev_out != nullptr, "pcl_pack_particles_device: dev_out is null");
+    hipLaunchKernelGGL(pcl::pack_aos_kernel, dim3(linear_grid(h, count)), dim3(pcl::kBlockThreads), 0,
+                       h->stream, soa_of(h, h->cur), h->ty, (unsigned long long)first,
+                       (unsigned long long)count, reinterpret_cast<pcl::ParticleAoS*>(dev_out));
+    PCL_HIP_TRY(hipGetLastError());
+    return PCL_OK;
+}
+
+int pcl_diagnostics_read(pcl_compute* h, pcl_diagnostics* out)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_REQUIRE(out != nullptr, "pcl_diagnostics_read: out is null");
+    if (int rc = ensure_diag(h)) return rc;
+    PCL_HIP_TRY(hipMemcpyAsync(out, h->d_diag, sizeof(pcl_diagnostics), hipMemcpyDeviceToHost, h->stream));
+    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+    return PCL_OK;
+}
+
+int pcl_diagnostics_device(pcl_compute* h, void* dev_out)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_REQUIRE(dev_out != nullptr, "pcl_diagnostics_device: dev_out is null");
+    if (int rc = ensure_diag(h)) return rc;
+    PCL_HIP_TRY(hipMemcpyAsync(dev_out, h->d_diag, sizeof(pcl_diagnostics), hipMemcpyDeviceToDevice, h->stream));
+    return PCL_OK;
+}
+
+int pcl_debug_cell_indices(pcl_compute* h, uint32_t* out, size_t first, size_t count)
+{
+    if (int rc = bind(h)) return rc;
+    if (int rc = check_range(first, count, h->n, "pcl_debug_cell_indices")) return rc;
+    if (count == 0) return PCL_OK;
+    PCL_REQUIRE(out != nullptr, "pcl_debug_cell_indices: out is null");
+    PCL_REQUIRE(h->n_cells >= 1, "the force grid is empty");
+    uint32_t* d = nullptr;
+    PCL_HIP_TRY(hipMalloc((void**)&d, count * sizeof(uint32_t)));
+    hipLaunchKernelGGL(pcl::cell_index_kernel, dim3(linear_grid(h, count)), dim3(pcl::kBlockThreads), 0,
+                       h->stream, soa_of(h, h->cur), (unsigned long long)first, (unsigned long long)count,
+                       uniforms_of(h), d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, count * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(PCL_ERR_HIP, std::string("pcl_debug_cell_indices: ") + hipGetErrorString(e));
+    return PCL_OK;
+}
+
+int pcl_set_stream(pcl_compute* h, void* hip_stream)
+{
+    if (int rc = bind(h)) return rc;
+    hipStream_t next = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    if (next != h->stream) PCL_HIP_TRY(hipStreamSynchronize(h->stream));  // keep work ordered across the switch
+    h->stream = next;
+    return PCL_OK;
+}
+
+int pcl_synchronize(pcl_compute* h)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+    return PCL_OK;
+}
+
+int pcl_timer_start(pcl_compute* h)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+    return PCL_OK;
+}
+
+int pcl_timer_stop(pcl_compute* h, float* elapsed_ms)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_REQUIRE(elapsed_ms != nullptr, "pcl_timer_stop: elapsed_ms is null");
+    PCL_HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+    PCL_HIP_TRY(hipEventSynchronize(h->ev_stop));
+    PCL_HIP_TRY(hipEventElapsedTime(elapsed_ms, h->ev_start, h->ev_stop));
+    return PCL_OK;
+}
+
+int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks, uint32_t* block_threads,
+                        uint32_t* particles_per_lane)
+{
+    if (!h) return fail(PCL_ERR_INVALID, "null handle");
+    if (grid_blocks) *grid_blocks = stream_grid(h, h->n);
+    if (block_threads) *block_threads = pcl::kBlockThreads;
+    if (particles_per_lane) *particles_per_lane = pcl::kParticlesPerLane;
+    return PCL_OK;
+}
+
+int pcl_set_tuning(pcl_compute* h, uint32_t grid_blocks, uint32_t variant)
+{
+    if (!h) return fail(PCL_ERR_INVALID, "null handle");
+    h->grid_cap = grid_blocks;
+    h->variant = variant;
+    return PCL_OK;
+}
+
+}  // extern "C"

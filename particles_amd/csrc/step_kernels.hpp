@@ -1,0 +1,565 @@
+// step_kernels.hpp — gfx950 device code of the particle update.
+//
+// The arithmetic follows src/compute.wgsl of the reference statement by
+// statement (citations below are relative to the reference checkout) and uses
+// only IEEE-754 correctly rounded fp32 operations (+, -, *, /, sqrt, compares,
+// float->u32 truncation) with FMA contraction disabled, so that on finite
+// inputs the streaming path is bit-for-bit reproducible on any IEEE machine.
+// exp(-delta_t) is the same for every particle and is evaluated once on the
+// host.  Layout: structure-of-arrays fp32 state (x,y,z,vx,vy,vz), one byte of
+// type per particle, field cells as float4 (only xyz is read).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace pcl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBlockThreads = 256;     // 4 waves of 64
+constexpr int kParticlesPerLane = 4;   // one 16-byte access per array per lane
+constexpr int kTileParticles = kBlockThreads * kParticlesPerLane;
+
+// Everything that is uniform over a launch; passed by value (lives in SGPRs).
+struct StepUniforms {
+    float decay;         // exp(-delta_t), evaluated on the host       wgsl:151
+    float dt;            // delta_t
+    float max_velocity;  //                                            wgsl:159
+    float radius;        // bounding_volume_radius                     wgsl:170
+    float two_radius;    // 2.0 * radius                               wgsl:60,63
+    float slh;           // (radius * 2.0) * 0.5                       wgsl:83,147
+    float neg_slh;       // -slh
+    float span_a;        // slh - (-slh)                               wgsl:75
+    float span_b[3];     // f32(dim) - 0.0                             wgsl:77
+    uint32_t dim_y;
+    uint32_t dim_z;
+    uint32_t last_cell;  // n_cells - 1: index clamp for the fetch
+    uint32_t degenerate; // start_a == end_a                           wgsl:69
+    float mass[5];       // particle_type_masses[k].mass               wgsl:109
+};
+
+struct DiagPartial {
+    double kinetic_energy;
+    unsigned long long count;
+    float pos_max[3];
+    float neg_pos_min[3];
+    float pad[2];
+};
+
+struct StateSoA {
+    float* a[6];  // x, y, z, vx, vy, vz
+};
+
+// ---------------------------------------------------------------- helpers
+
+// wgsl:68-79 with start_b = 0; the uniform operands are precomputed.
+__device__ __forceinline__ float map_range_axis(const StepUniforms& U, float val, float span_b)
+{
+    const float valc = fminf(fmaxf(val, U.neg_slh), U.slh);
+    const float oz = __fdiv_rn(valc - U.neg_slh, U.span_a);
+    return oz * span_b + 0.0f;
+}
+
+// wgsl:81-89 and the fetch of wgsl:147-148; an index past the end is clamped
+// to the last cell.
+__device__ __forceinline__ uint32_t cell_index(const StepUniforms& U, float x, float y, float z)
+{
+    uint32_t ixx = 0u, ixy = 0u, ixz = 0u;
+    if (!U.degenerate) {
+        ixx = (uint32_t)map_range_axis(U, x, U.span_b[0]);
+        ixy = (uint32_t)map_range_axis(U, y, U.span_b[1]);
+        ixz = (uint32_t)map_range_axis(U, z, U.span_b[2]);
+    }
+    const uint32_t fgi = ixx * U.dim_y * U.dim_z + ixy * U.dim_z + ixz;
+    return fgi < U.last_cell ? fgi : U.last_cell;
+}
+
+// wgsl:58-66
+__device__ __forceinline__ float wrap_symmetrically(float val, float max, float two_max)
+{
+    if (val > max) return val - two_max;
+    if (val < -max) return val + two_max;
+    return val;
+}
+
+__device__ __forceinline__ float mass_of(const StepUniforms& U, uint32_t ty)
+{
+    float m = U.mass[4];
+    m = ty == 3u ? U.mass[3] : m;
+    m = ty == 2u ? U.mass[2] : m;
+    m = ty == 1u ? U.mass[1] : m;
+    m = ty == 0u ? U.mass[0] : m;
+    return m;
+}
+
+// wgsl:148-172 for one particle whose pair acceleration is (ax, ay, az) and
+// whose field cell value is f.
+__device__ __forceinline__ void integrate(const StepUniforms& U, float fx, float fy, float fz,
+                                          float m, float ax, float ay, float az,
+                                          float& x, float& y, float& z,
+                                          float& vx, float& vy, float& vz)
+{
+    ax = ax + __fdiv_rn(10.0f * fx, m);
+    ay = ay + __fdiv_rn(10.0f * fy, m);
+    az = az + __fdiv_rn(10.0f * fz, m);
+
+    vx = vx * U.decay;
+    vy = vy * U.decay;
+    vz = vz * U.decay;
+    vx = vx + ax * U.dt;
+    vy = vy + ay * U.dt;
+    vz = vz + az * U.dt;
+
+    const float vel = __fsqrt_rn((vx * vx + vy * vy) + vz * vz);
+    if (vel > 0.001f) {
+        const float capped = fminf(fmaxf(vel, 0.0f), U.max_velocity);
+        vx = __fdiv_rn(vx, vel) * capped;
+        vy = __fdiv_rn(vy, vel) * capped;
+        vz = __fdiv_rn(vz, vel) * capped;
+    }
+
+    x = x + vx * U.dt;
+    y = y + vy * U.dt;
+    z = z + vz * U.dt;
+
+    x = wrap_symmetrically(x, U.radius, U.two_radius);
+    y = wrap_symmetrically(y, U.radius, U.two_radius);
+    z = wrap_symmetrically(z, U.radius, U.two_radius);
+}
+
+// ------------------------------------------------------- diagnostics pieces
+
+struct DiagAcc {
+    double ke;
+    unsigned long long count;
+    float mx[3];
+    float nmn[3];
+    __device__ __forceinline__ void init()
+    {
+        ke = 0.0;
+        count = 0ull;
+        for (int c = 0; c < 3; ++c) { mx[c] = -INFINITY; nmn[c] = -INFINITY; }
+    }
+    __device__ __forceinline__ void add(float m, float x, float y, float z,
+                                        float vx, float vy, float vz)
+    {
+        const double dx = vx, dy = vy, dz = vz;
+        ke += 0.5 * (double)m * ((dx * dx + dy * dy) + dz * dz);
+        count += 1ull;
+        mx[0] = fmaxf(mx[0], x);  mx[1] = fmaxf(mx[1], y);  mx[2] = fmaxf(mx[2], z);
+        nmn[0] = fmaxf(nmn[0], -x); nmn[1] = fmaxf(nmn[1], -y); nmn[2] = fmaxf(nmn[2], -z);
+    }
+};
+
+__device__ __forceinline__ double shfl_down_f64(double v, int delta)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_down(lo, delta, 64);
+    hi = __shfl_down(hi, delta, 64);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ unsigned long long shfl_down_u64(unsigned long long v, int delta)
+{
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl_down(lo, delta, 64);
+    hi = __shfl_down(hi, delta, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Reduce one accumulator per thread to one DiagPartial per block, in a fixed
+// order (wave tree, then waves 0..3 in sequence): deterministic for a given
+// launch geometry.
+__device__ __forceinline__ void block_reduce_store(DiagAcc acc, DiagPartial* out)
+{
+    __shared__ DiagPartial wave_part[kBlockThreads / 64];
+    for (int d = 32; d >= 1; d >>= 1) {
+        acc.ke += shfl_down_f64(acc.ke, d);
+        acc.count += shfl_down_u64(acc.count, d);
+        for (int c = 0; c < 3; ++c) {
+            acc.mx[c] = fmaxf(acc.mx[c], __shfl_down(acc.mx[c], d, 64));
+            acc.nmn[c] = fmaxf(acc.nmn[c], __shfl_down(acc.nmn[c], d, 64));
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        DiagPartial p;
+        p.kinetic_energy = acc.ke;
+        p.count = acc.count;
+        for (int c = 0; c < 3; ++c) { p.pos_max[c] = acc.mx[c]; p.neg_pos_min[c] = acc.nmn[c]; }
+        p.pad[0] = p.pad[1] = 0.0f;
+        wave_part[wave] = p;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        DiagPartial p = wave_part[0];
+        for (int w = 1; w < kBlockThreads / 64; ++w) {
+            p.kinetic_energy += wave_part[w].kinetic_energy;
+            p.count += wave_part[w].count;
+            for (int c = 0; c < 3; ++c) {
+                p.pos_max[c] = fmaxf(p.pos_max[c], wave_part[w].pos_max[c]);
+                p.neg_pos_min[c] = fmaxf(p.neg_pos_min[c], wave_part[w].neg_pos_min[c]);
+            }
+        }
+        *out = p;
+    }
+}
+
+// Diagnostics record as the C ABI lays it out (pcl_diagnostics, 48 bytes).
+struct DiagOut {
+    double count;
+    double kinetic_energy;
+    float pos_max[3];
+    float neg_pos_min[3];
+    float pad[2];
+};
+
+// One block: fold `n_partials` block partials, in index order per thread and
+// then through the same fixed tree.
+__global__ __launch_bounds__(kBlockThreads) void diag_finalize_kernel(
+    const DiagPartial* __restrict__ partials, uint32_t n_partials, DiagOut* __restrict__ out)
+{
+    __shared__ DiagPartial folded;
+    DiagAcc acc;
+    acc.init();
+    for (uint32_t i = threadIdx.x; i < n_partials; i += kBlockThreads) {
+        const DiagPartial p = partials[i];
+        acc.ke += p.kinetic_energy;
+        acc.count += p.count;
+        for (int c = 0; c < 3; ++c) {
+            acc.mx[c] = fmaxf(acc.mx[c], p.pos_max[c]);
+            acc.nmn[c] = fmaxf(acc.nmn[c], p.neg_pos_min[c]);
+        }
+    }
+    block_reduce_store(acc, &folded);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        DiagOut o;
+        o.count = (double)folded.count;
+        o.kinetic_energy = folded.kinetic_energy;
+        for (int c = 0; c < 3; ++c) { o.pos_max[c] = folded.pos_max[c]; o.neg_pos_min[c] = folded.neg_pos_min[c]; }
+        o.pad[0] = o.pad[1] = 0.0f;
+        *out = o;
+    }
+}
+
+// ------------------------------------------------------ streaming kernel K1
+
+struct StreamArgs {
+    const float* __restrict__ src[6];
+    float* __restrict__ dst[6];
+    const uint8_t* __restrict__ ty;
+    const f32x4* __restrict__ field;
+    unsigned long long n;
+    DiagPartial* partials;  // one per block when DIAG
+    uint32_t lds_cells;     // cells staged in LDS when FIELD_LDS
+};
+
+template <bool NT>
+__device__ __forceinline__ f32x4 load4(const float* base, unsigned long long group)
+{
+    const f32x4* p = reinterpret_cast<const f32x4*>(base) + group;
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+template <bool NT>
+__device__ __forceinline__ void store4(float* base, unsigned long long group, f32x4 v)
+{
+    f32x4* p = reinterpret_cast<f32x4*>(base) + group;
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+// Pair term provably zero (every polynomial coefficient +-0, or no distance
+// can pass both cut-offs): wgsl:115-144 contributes exactly +0, so the update
+// is a pure stream: 24 B state + 1 B type in, 24 B out per particle, plus one
+// cache-resident 16-byte field fetch.  Persistent grid, grid-stride over
+// groups of 4 consecutive particles per lane.
+template <bool DIAG, bool NT, bool FIELD_LDS>
+__global__ __launch_bounds__(kBlockThreads) void step_stream_kernel(StreamArgs a, StepUniforms U)
+{
+    // Small fields (<= 64 KiB) are staged in LDS once per persistent block;
+    // larger ones are fetched through L2 / Infinity Cache.
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds_field[];
+    if (FIELD_LDS) {
+        for (uint32_t c = threadIdx.x; c < a.lds_cells; c += kBlockThreads) lds_field[c] = a.field[c];
+        __syncthreads();
+    }
+    auto fetch = [&](uint32_t c) -> f32x4 { return FIELD_LDS ? lds_field[c] : a.field[c]; };
+
+    DiagAcc acc;
+    if (DIAG) acc.init();
+
+    const unsigned long long n_groups = a.n / 4ull;
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
+    for (unsigned long long g = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x;
+         g < n_groups; g += stride) {
+        f32x4 X = load4<NT>(a.src[0], g);
+        f32x4 Y = load4<NT>(a.src[1], g);
+        f32x4 Z = load4<NT>(a.src[2], g);
+        f32x4 VX = load4<NT>(a.src[3], g);
+        f32x4 VY = load4<NT>(a.src[4], g);
+        f32x4 VZ = load4<NT>(a.src[5], g);
+        const uint32_t t4 = NT ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.ty) + g)
+                               : reinterpret_cast<const uint32_t*>(a.ty)[g];
+
+        uint32_t cell[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cell[k] = cell_index(U, X[k], Y[k], Z[k]);
+        f32x4 F[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) F[k] = fetch(cell[k]);
+
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float m = mass_of(U, (t4 >> (8 * k)) & 0xFFu);
+            float x = X[k], y = Y[k], z = Z[k], vx = VX[k], vy = VY[k], vz = VZ[k];
+            integrate(U, F[k].x, F[k].y, F[k].z, m, 0.0f, 0.0f, 0.0f, x, y, z, vx, vy, vz);
+            X[k] = x; Y[k] = y; Z[k] = z; VX[k] = vx; VY[k] = vy; VZ[k] = vz;
+            if (DIAG) acc.add(m, x, y, z, vx, vy, vz);
+        }
+
+        store4<NT>(a.dst[0], g, X);
+        store4<NT>(a.dst[1], g, Y);
+        store4<NT>(a.dst[2], g, Z);
+        store4<NT>(a.dst[3], g, VX);
+        store4<NT>(a.dst[4], g, VY);
+        store4<NT>(a.dst[5], g, VZ);
+    }
+
+    // Up to 3 particles past the last full group: block 0, lanes 0..2.
+    const unsigned long long tail = n_groups * 4ull + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 3 && tail < a.n) {
+        float x = a.src[0][tail], y = a.src[1][tail], z = a.src[2][tail];
+        float vx = a.src[3][tail], vy = a.src[4][tail], vz = a.src[5][tail];
+        const float m = mass_of(U, a.ty[tail]);
+        const f32x4 f = fetch(cell_index(U, x, y, z));
+        integrate(U, f.x, f.y, f.z, m, 0.0f, 0.0f, 0.0f, x, y, z, vx, vy, vz);
+        a.dst[0][tail] = x; a.dst[1][tail] = y; a.dst[2][tail] = z;
+        a.dst[3][tail] = vx; a.dst[4][tail] = vy; a.dst[5][tail] = vz;
+        if (DIAG) acc.add(m, x, y, z, vx, vy, vz);
+    }
+
+    if (DIAG) block_reduce_store(acc, a.partials + blockIdx.x);
+}
+
+// -------------------------------------------------------- general kernel K2
+
+// Parameter block as the reference lays it out (912 bytes): wgsl:17-28.
+struct ParamsBlock {
+    float polys[25][8];
+    float masses[5][4];
+    uint32_t dims[3];
+    float delta_t, max_velocity, radius, cut_off_distance, distance_exponent;
+};
+
+// wgsl:51-56, in the shader's left-to-right order (not Horner).
+__device__ __forceinline__ float eval_poly7(float x, const float* c)
+{
+    const float x2 = x * x;
+    const float x4 = x2 * x2;
+    const float x3 = x2 * x;
+    float r = (c[7] * x4) * x3;
+    r = r + (c[6] * x3) * x3;
+    r = r + (c[5] * x2) * x3;
+    r = r + c[4] * x4;
+    r = r + c[3] * x3;
+    r = r + c[2] * x2;
+    r = r + c[1] * x;
+    r = r + c[0];
+    return r;
+}
+
+struct PairArgs {
+    const float* __restrict__ src[6];
+    float* __restrict__ dst[6];
+    const uint8_t* __restrict__ ty;
+    const f32x4* __restrict__ field;
+    const ParamsBlock* __restrict__ params;
+    unsigned long long n;
+    DiagPartial* partials;
+};
+
+// All-pairs attraction (wgsl:111-144) tiled through LDS: a block owns 256
+// particles, every tile of 256 source particles is staged once per block as
+// (x, y, z, type) and swept by all lanes in index order, so each particle's
+// sum is accumulated in the shader's order j = 0..N-1.
+template <bool DIAG>
+__global__ __launch_bounds__(kBlockThreads) void step_pairs_kernel(PairArgs a, StepUniforms U)
+{
+    __shared__ f32x4 tile[kBlockThreads];
+    __shared__ float polys[25 * 8];
+
+    for (int k = threadIdx.x; k < 25 * 8; k += kBlockThreads)
+        polys[k] = a.params->polys[k / 8][k % 8];
+    const float cut_off = a.params->cut_off_distance;
+    const float exponent = a.params->distance_exponent;
+
+    const unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x;
+    const bool live = i < a.n;
+    float x = 0.f, y = 0.f, z = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
+    uint32_t my_ty = 0u;
+    if (live) {
+        x = a.src[0][i]; y = a.src[1][i]; z = a.src[2][i];
+        vx = a.src[3][i]; vy = a.src[4][i]; vz = a.src[5][i];
+        my_ty = a.ty[i];
+    }
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+
+    for (unsigned long long base = 0; base < a.n; base += kBlockThreads) {
+        __syncthreads();
+        const unsigned long long j = base + threadIdx.x;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (j < a.n) {
+            t.x = a.src[0][j]; t.y = a.src[1][j]; t.z = a.src[2][j];
+            t.w = __uint_as_float((uint32_t)a.ty[j]);
+        }
+        tile[threadIdx.x] = t;
+        __syncthreads();
+        const unsigned long long rem = a.n - base;
+        const int cnt = rem < (unsigned long long)kBlockThreads ? (int)rem : kBlockThreads;
+        if (live) {
+            for (int jj = 0; jj < cnt; ++jj) {
+                if (base + jj == i) continue;                       // wgsl:120-122
+                const f32x4 o = tile[jj];
+                const float dx = o.x - x, dy = o.y - y, dz = o.z - z;
+                const float len = __fsqrt_rn((dx * dx + dy * dy) + dz * dz);
+                if (len < 0.001f) continue;                         // wgsl:126-128
+                if (len > cut_off) continue;                        // wgsl:129-131
+                // pow(x, 0) is exactly 1 for every finite positive x
+                const float df = exponent == 0.0f ? 1.0f : powf(len, exponent);
+                const uint32_t oty = __float_as_uint(o.w);
+                const float m2 = mass_of(U, oty);
+                const float pv = eval_poly7(len, &polys[(oty + my_ty * 5u) * 8u]);
+                ax = ax + ((__fdiv_rn(dx, len) * pv) * m2) * df;    // wgsl:139
+                ay = ay + ((__fdiv_rn(dy, len) * pv) * m2) * df;
+                az = az + ((__fdiv_rn(dz, len) * pv) * m2) * df;
+            }
+        }
+    }
+
+    DiagAcc acc;
+    if (DIAG) acc.init();
+    if (live) {
+        const float m = mass_of(U, my_ty);
+        const f32x4 f = a.field[cell_index(U, x, y, z)];
+        integrate(U, f.x, f.y, f.z, m, ax, ay, az, x, y, z, vx, vy, vz);
+        a.dst[0][i] = x; a.dst[1][i] = y; a.dst[2][i] = z;
+        a.dst[3][i] = vx; a.dst[4][i] = vy; a.dst[5][i] = vz;
+        if (DIAG) acc.add(m, x, y, z, vx, vy, vz);
+    }
+    if (DIAG) block_reduce_store(acc, a.partials + blockIdx.x);
+}
+
+// ------------------------------------------------- standalone diagnostics K3
+
+__global__ __launch_bounds__(kBlockThreads) void diag_reduce_kernel(
+    StateSoA s, const uint8_t* __restrict__ ty, unsigned long long n, StepUniforms U,
+    DiagPartial* partials)
+{
+    DiagAcc acc;
+    acc.init();
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x;
+         i < n; i += stride)
+        acc.add(mass_of(U, ty[i]), s.a[0][i], s.a[1][i], s.a[2][i], s.a[3][i], s.a[4][i], s.a[5][i]);
+    block_reduce_store(acc, partials + blockIdx.x);
+}
+
+// -------------------------------------------------- layout conversion K4
+
+// 48-byte record of the reference: pos vec4 @0, vel vec4 @16, ty u32 @32.
+struct ParticleAoS {
+    float pos[4];
+    float vel[4];
+    uint32_t ty;
+    uint32_t pad[3];
+};
+
+__global__ __launch_bounds__(kBlockThreads) void unpack_aos_kernel(
+    const ParticleAoS* __restrict__ in, unsigned long long count, StateSoA s,
+    uint8_t* __restrict__ ty, unsigned long long first)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x;
+         i < count; i += stride) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(in[i].pos);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in[i].vel);
+        const unsigned long long o = first + i;
+        s.a[0][o] = p.x; s.a[1][o] = p.y; s.a[2][o] = p.z;
+        s.a[3][o] = v.x; s.a[4][o] = v.y; s.a[5][o] = v.z;
+        ty[o] = (uint8_t)in[i].ty;
+    }
+}
+
+// Writes what wgsl:180 writes: w lanes 1.0, padding 0.
+__global__ __launch_bounds__(kBlockThreads) void pack_aos_kernel(
+    StateSoA s, const uint8_t* __restrict__ ty, unsigned long long first,
+    unsigned long long count, ParticleAoS* __restrict__ out)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x;
+         i < count; i += stride) {
+        const unsigned long long o = first + i;
+        const f32x4 p = {s.a[0][o], s.a[1][o], s.a[2][o], 1.0f};
+        const f32x4 v = {s.a[3][o], s.a[4][o], s.a[5][o], 1.0f};
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 t = {(uint32_t)ty[o], 0u, 0u, 0u};
+        *reinterpret_cast<f32x4*>(out[i].pos) = p;
+        *reinterpret_cast<f32x4*>(out[i].vel) = v;
+        *reinterpret_cast<u32x4*>(&out[i].ty) = t;
+    }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void cell_index_kernel(
+    StateSoA s, unsigned long long first, unsigned long long count, StepUniforms U,
+    uint32_t* __restrict__ out)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x;
+         i < count; i += stride) {
+        const unsigned long long o = first + i;
+        out[i] = cell_index(U, s.a[0][o], s.a[1][o], s.a[2][o]);
+    }
+}
+
+// --------------------------------------------- seeded synthetic scene
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ float synth_uniform(unsigned long long seed, unsigned long long g,
+                                               uint32_t axis)
+{
+    const unsigned long long h = mix64(seed ^ mix64(g * 8ull + (unsigned long long)axis));
+    return (float)(uint32_t)(h >> 40) * (1.0f / 16777216.0f);
+}
+
+// Distribution of src/main.rs:41-48,156-169: extent * (u - 0.5), ty = index % 5.
+__global__ __launch_bounds__(kBlockThreads) void generate_kernel(
+    StateSoA s, uint8_t* __restrict__ ty, unsigned long long n, unsigned long long seed,
+    unsigned long long first_global, float pos_extent, float vel_extent)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x;
+         i < n; i += stride) {
+        const unsigned long long g = first_global + i;
+#pragma unroll
+        for (uint32_t c = 0; c < 3; ++c) {
+            s.a[c][i] = pos_extent * (synth_uniform(seed, g, c) - 0.5f);
+            s.a[3 + c][i] = vel_extent * (synth_uniform(seed, g, 3u + c) - 0.5f);
+        }
+        ty[i] = (uint8_t)(g % 5ull);
+    }
+}
+
+}  // namespace pcl

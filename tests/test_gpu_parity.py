@@ -1,0 +1,208 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Bit-exact for positions, velocities and cell indices on
+the streaming path and on the pair path with distance_exponent = 0; relative
+tolerance 1e-5 (north-star bar) where powf is involved."""
+import numpy as np
+import pytest
+
+import particles_amd as pa
+from conftest import assert_particles_bit_equal, scene_swirl_field
+
+pytestmark = pytest.mark.gpu
+
+DT = np.float32(1.0 / 60.0)
+
+
+def default_scene():
+    sp = pa.SimParams()
+    p = pa.lattice_particles((5.0, 2.0, 2.0), 10, 10, 10)          # src/main.rs:225-231
+    g = sp.new_force_grid_centered().get_force_vectors()             # src/main.rs:142-147,235
+    return sp, p, g
+
+
+def test_default_scene_16_steps_bit_exact(oracle):
+    sp, p, g = default_scene()
+    sp.delta_t = DT
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        for k in range(1, 17):
+            c.compute()
+            if k in (1, 2, 15, 16):  # odd and even ping-pong positions
+                want = oracle.run(sp, p, g, k, mode=oracle.MODE_ALWAYS_PAIRS)
+                assert_particles_bit_equal(c.read_particles(), want, f"default scene, step {k}")
+        assert c.last_step_kernel == pa.KERNEL_STREAM
+        assert c.step_count == 16
+
+
+def test_new_starts_with_default_params_dt0(oracle):
+    # src/compute.rs:33: Compute::new uploads its own SimParams::new() (delta_t = 0)
+    sp, p, g = default_scene()
+    with pa.Compute.new(p, g) as c:
+        c.compute()
+        want = oracle.run(pa.SimParams(), p, g, 1)
+        assert_particles_bit_equal(c.read_particles(), want, "dt=0 step")
+        # positions unchanged by a dt = 0 step
+        assert np.array_equal(c.read_particles()["pos"][:, :3], p["pos"][:, :3])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 63, 64, 255, 256, 1023, 1024, 1025, 4099, 100003])
+def test_stream_kernel_ragged_sizes(oracle, n):
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = (16, 8, 4)
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    g = scene_swirl_field(16, 8, 4, 10.0, seed=7)
+    p = oracle.synth_particles(n, seed=1000 + n, pos_extent=20.0, vel_extent=10.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        assert np.array_equal(c.debug_cell_indices(), oracle.cell_indices(sp, p, g.shape[0]))
+        for _ in range(5):
+            c.compute()
+        want = oracle.run(sp, p, g, 5, mode=oracle.MODE_SKIP_INERT)
+        assert_particles_bit_equal(c.read_particles(), want, f"n={n}")
+        assert np.array_equal(c.debug_cell_indices(), oracle.cell_indices(sp, want, g.shape[0]))
+
+
+def test_empty_particle_set():
+    sp, p, g = default_scene()
+    with pa.Compute.new(p[:0], g) as c:
+        assert c.num_particles == 0
+        c.compute()
+        assert c.read_particles().shape == (0,)
+        assert c.diagnostics()["count"] == 0
+
+
+def test_device_generator_matches_oracle(oracle):
+    sp, p, g = default_scene()
+    with pa.Compute.new(p, g) as c:
+        c.generate_particles(5000, seed=42, first_global_index=123456789012, pos_extent=20.0, vel_extent=10.0)
+        want = oracle.synth_particles(5000, seed=42, first_global_index=123456789012, pos_extent=20.0, vel_extent=10.0)
+        assert_particles_bit_equal(c.read_particles(), want, "synthetic scene")
+
+
+def pair_params(exponent):
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    sp.cut_off_distance = 1.5
+    sp.distance_exponent = exponent
+    rng = np.random.default_rng(99)
+    sp.polys[:] = rng.uniform(-2.0, 2.0, size=(25, 8)).astype(np.float32)
+    return sp
+
+
+@pytest.mark.parametrize("n", [2, 257, 1000, 3001])
+def test_pair_kernel_exponent0_bit_exact(oracle, n):
+    sp = pair_params(0.0)
+    g = sp.new_force_grid_centered().get_force_vectors()
+    p = oracle.synth_particles(n, seed=5, pos_extent=4.0, vel_extent=10.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        for _ in range(3):
+            c.compute()
+        assert c.last_step_kernel == pa.KERNEL_PAIRS
+        want = oracle.run(sp, p, g, 3)
+        assert_particles_bit_equal(c.read_particles(), want, f"pairs n={n}")
+
+
+@pytest.mark.parametrize("exponent", [-2.0, 1.5])
+def test_pair_kernel_powf_within_tolerance(oracle, exponent):
+    sp = pair_params(exponent)
+    g = sp.new_force_grid_centered().get_force_vectors()
+    p = oracle.synth_particles(1500, seed=6, pos_extent=4.0, vel_extent=10.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        c.compute()
+        got = c.read_particles()
+    want = oracle.run(sp, p, g, 1)
+    # single step, identical inputs: |a-b| <= 1e-5*max(|a|,|b|) + 1e-6, positions
+    # compared modulo the wrap (2r)
+    two_r = 2.0 * sp.bounding_volume_radius
+    dpos = np.abs(got["pos"][:, :3] - want["pos"][:, :3])
+    dpos = np.minimum(dpos, np.abs(two_r - dpos))
+    tol_pos = 1e-5 * np.maximum(np.abs(got["pos"][:, :3]), np.abs(want["pos"][:, :3])) + 1e-6
+    tol_vel = 1e-5 * np.maximum(np.abs(got["vel"][:, :3]), np.abs(want["vel"][:, :3])) + 1e-6
+    assert np.all(dpos <= tol_pos)
+    assert np.all(np.abs(got["vel"][:, :3] - want["vel"][:, :3]) <= tol_vel)
+
+
+def test_stream_equals_pair_kernel_with_zero_polys(oracle):
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    g = sp.new_force_grid_centered().get_force_vectors()
+    p = oracle.synth_particles(2000, seed=8, pos_extent=2.0, vel_extent=10.0)
+    res = []
+    for forced in (False, True):
+        with pa.Compute.new(p, g) as c:
+            c.update_sim_params(sp)
+            c.force_pair_kernel(forced)
+            for _ in range(4):
+                c.compute()
+            assert c.last_step_kernel == (pa.KERNEL_PAIRS if forced else pa.KERNEL_STREAM)
+            res.append(c.read_particles())
+    assert_particles_bit_equal(res[0], res[1], "stream vs pairs")
+
+
+def test_diagnostics_match_oracle(oracle):
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    g = sp.new_force_grid_centered().get_force_vectors()
+    p = oracle.synth_particles(50001, seed=9, pos_extent=20.0, vel_extent=10.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        for fused in (False, True):
+            c.enable_step_diagnostics(fused)
+            c.compute()
+            d = c.diagnostics()
+            want = oracle.diagnostics(sp, c.read_particles())
+            assert d["count"] == want["count"] == 50001
+            assert abs(d["kinetic_energy"] - want["kinetic_energy"]) <= 1e-12 * want["kinetic_energy"]
+            assert np.array_equal(d["pos_max"], want["pos_max"])
+            assert np.array_equal(d["pos_min"], want["pos_min"])
+
+
+def test_field_patch_and_readback_ranges(oracle):
+    sp, p, g = default_scene()
+    sp.delta_t = DT
+    g2 = g.copy()
+    g2[100:200, :3] = np.float32(3.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        c.patch_force_grid(100, g2[100:200])
+        c.compute()
+        want = oracle.run(sp, p, g2, 1)
+        assert_particles_bit_equal(c.read_particles(), want, "patched field")
+        assert_particles_bit_equal(c.read_particles(17, 300), want[17:317], "sub-range")
+        soa = c.read_soa(5, 10)
+        assert np.array_equal(soa["x"], want["pos"][5:15, 0]) and np.array_equal(soa["ty"], want["ty"][5:15])
+        with pytest.raises(pa.PclError):
+            c.read_particles(990, 20)
+        with pytest.raises(pa.PclError):
+            c.patch_force_grid(990, g2[:20])
+
+
+def test_invalid_type_rejected():
+    sp, p, g = default_scene()
+    bad = p.copy()
+    bad["ty"][3] = 5
+    with pytest.raises(pa.PclError):
+        pa.Compute.new(bad, g)
+
+
+def test_lds_field_path_large_n(oracle):
+    # 10^3 cells = 16 KB: staged in LDS once n is large enough per persistent block
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    g = sp.new_force_grid_centered().get_force_vectors()
+    n = 1 << 20
+    with pa.Compute.new(pa.empty_particles(0), g) as c:
+        c.update_sim_params(sp)
+        c.set_tuning(grid_blocks=64)
+        c.generate_particles(n, seed=77, pos_extent=20.0, vel_extent=10.0)
+        c.compute()
+        c.compute()
+        got = c.read_particles(n - 5000, 5000)
+    p = oracle.synth_particles(5000, seed=77, first_global_index=n - 5000, pos_extent=20.0, vel_extent=10.0)
+    want = oracle.run(sp, p, g, 2, mode=oracle.MODE_SKIP_INERT)
+    assert_particles_bit_equal(got, want, "LDS-staged field")
