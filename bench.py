@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-frame particle update on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one launch of the update over every resident particle
+(``Compute::compute`` of the reference, src/compute.rs:221-227).  Workload per
+GPU (weak scaling): 2^28 particles, 1024 x 1024 x 1 field, the 256M-particle
+configuration the HBM target is quoted on; seeded synthetic inputs generated
+on the device: pos uniform over the whole bounding cube (worst case for the
+field fetch), vel = 10*(u-0.5), ty = i % 5, masses (1, .5, 2, 1.5, .75), zero
+force curves (the reference's default, so the streaming kernel runs), dt = 1/60.
+For N > 1 this script is started once per GPU by torch.distributed.run; ranks
+own disjoint index ranges, the field is created on rank 0 and replicated with
+one RCCL broadcast, and (with --diagnostics on) the per-step diagnostics are
+all-reduced.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak
+BYTES_PER_PARTICLE_STEP = 49     # 24 B state in + 1 B type in + 24 B state out (SoA fp32, u8 type)
+MASSES = (1.0, 0.5, 2.0, 1.5, 0.75)
+RADIUS = 10.0
+DT = 1.0 / 60.0
+
+
+def swirl_field(nx, ny, nz, radius, seed):
+    """(-y, x, 0)/r at the cell centres plus a seeded uniform [-1,1) perturbation."""
+    r = np.float32(radius)
+    cx = -r + (2 * r) * ((np.arange(nx, dtype=np.float32) + np.float32(0.5)) / np.float32(nx))
+    cy = -r + (2 * r) * ((np.arange(ny, dtype=np.float32) + np.float32(0.5)) / np.float32(ny))
+    px, py, _ = np.meshgrid(cx, cy, np.zeros(nz, dtype=np.float32), indexing="ij")
+    out = np.empty((nx * ny * nz, 4), dtype=np.float32)
+    out[:, 0] = (-py / r).ravel()
+    out[:, 1] = (px / r).ravel()
+    out[:, 2] = 0.0
+    rng = np.random.default_rng(seed)
+    out[:, :3] += rng.uniform(-1.0, 1.0, size=(nx * ny * nz, 3)).astype(np.float32)
+    out[:, 3] = 1.0
+    return out
+
+
+def make_params(pa, dims):
+    sp = pa.SimParams()
+    sp.delta_t = np.float32(DT)
+    sp.force_grid_dimensions = dims
+    sp.masses = MASSES
+    sp.bounding_volume_radius = RADIUS
+    sp.max_velocity = 100.0
+    return sp
+
+
+def cpu_baseline(sp, field, seed, pos_extent, budget_s=12.0):
+    """Time the CPU oracle (scalar C restatement of the shader, same pair-skip
+    rule, index-range split over host threads) on a bounded sample of the same
+    workload."""
+    from oracle import oracle as O
+    threads = max(1, min(16, O.max_threads(), os.cpu_count() or 1))
+    n = 1 << 22
+    p = O.synth_particles(n, seed, 0, pos_extent, 10.0)
+    O.step(sp, p, field, mode=O.MODE_SKIP_INERT, threads=threads)  # warm-up
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        p = O.step(sp, p, field, mode=O.MODE_SKIP_INERT, threads=threads)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or steps >= 64:
+            break
+    return {
+        "value": n * steps / el,
+        "unit": "particle-steps/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{steps} steps of {n} particles (same field, params and distributions), "
+                  f"C oracle -O3, {threads} OpenMP threads, {el:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--particles-per-gpu", type=int, default=1 << 28)
+    ap.add_argument("--field", type=int, nargs=3, default=(1024, 1024, 1), metavar=("NX", "NY", "NZ"))
+    ap.add_argument("--pos-extent", type=float, default=2.0 * RADIUS,
+                    help="positions are pos_extent*(u-0.5); 20 = whole cube, 2 = the reference's cluster")
+    ap.add_argument("--diagnostics", choices=("on", "off"), default="off",
+                    help="fuse count/kinetic-energy/bounds into the step and all-reduce them per step")
+    ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--grid-blocks", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import particles_amd as pa
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    dims = tuple(args.field)
+    n_cells = dims[0] * dims[1] * dims[2]
+    n_local = args.particles_per_gpu
+    sp = make_params(pa, dims)
+
+    # Field: built on rank 0, replicated with one broadcast over RCCL.
+    field_host = swirl_field(*dims, RADIUS, args.seed) if rank == 0 else None
+    stream = torch.cuda.current_stream()
+    c = pa.Compute.new(pa.empty_particles(0), np.zeros((1, 4), dtype=np.float32), device=local_rank)
+    c.set_stream(stream.cuda_stream)
+    c.set_tuning(args.grid_blocks, args.variant)
+    if world > 1:
+        field_dev = torch.empty((n_cells, 4), dtype=torch.float32, device="cuda")
+        if rank == 0:
+            field_dev.copy_(torch.from_numpy(field_host))
+        dist.broadcast(field_dev, src=0)
+        c.update_force_grid_device(field_dev.data_ptr(), n_cells)
+    else:
+        c.update_force_grid(field_host)
+    c.update_sim_params(sp)
+    c.generate_particles(n_local, args.seed, first_global_index=rank * n_local,
+                         pos_extent=args.pos_extent, vel_extent=10.0)
+    diag_on = args.diagnostics == "on"
+    c.enable_step_diagnostics(diag_on)
+    diag_dev = torch.zeros(48, dtype=torch.uint8, device="cuda") if diag_on else None
+    pending = []
+
+    def one_step():
+        c.compute()
+        if diag_on:
+            c.diagnostics_device(diag_dev.data_ptr())
+            if world > 1:
+                sums = diag_dev[:16].view(torch.float64)     # count, kinetic energy
+                maxs = diag_dev[16:40].view(torch.float32)   # max xyz, -min xyz
+                pending.append(dist.all_reduce(sums, op=dist.ReduceOp.SUM, async_op=True))
+                pending.append(dist.all_reduce(maxs, op=dist.ReduceOp.MAX, async_op=True))
+                while len(pending) > 8:
+                    pending.pop(0).wait()
+
+    def fence():
+        while pending:
+            pending.pop(0).wait()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    c.timer_start()
+    for _ in range(args.steps):
+        one_step()
+    kernel_ms = c.timer_stop() / max(1, args.steps)   # HIP events on the kernel's stream
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    diag = c.diagnostics() if rank == 0 else None
+    geometry = c.launch_geometry()
+    kernel = c.last_step_kernel
+
+    if rank == 0:
+        total = n_local * world
+        value = total * args.steps / elapsed
+        achieved = n_local * BYTES_PER_PARTICLE_STEP / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "particle-steps/sec",
+            "value": value,
+            "unit": "particle-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n_local} particles per GPU ({total} total), "
+                            f"{dims[0]}x{dims[1]}x{dims[2]} static vector field, fp32 SoA, pair term inert",
+                "particles_per_gpu": n_local,
+                "field_dims": list(dims),
+                "pos_extent": args.pos_extent,
+                "diagnostics_per_step": diag_on,
+                "parallelism": f"particle-sharded x{world}, field replicated by RCCL broadcast",
+                "kernel": {1: "step_stream_kernel", 2: "step_pairs_kernel"}.get(kernel, "none"),
+                "launch": geometry,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_particle_step": BYTES_PER_PARTICLE_STEP,
+                "kernel_ms": kernel_ms,
+            },
+            "final_kinetic_energy_rank0": diag["kinetic_energy"],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sp, field_host, args.seed, args.pos_extent)
+        print(json.dumps(out), flush=True)
+
+    c.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -59,6 +59,8 @@ int fail(int code, const std::string& msg)
 
 constexpr size_t kStagingRecords = size_t(1) << 22;  // AoS staging chunk: 4 Mi records = 192 MiB
 constexpr uint32_t kLdsFieldMaxBytes = 64u * 1024u;  // fields up to this size are staged in LDS
+constexpr size_t kArrayStagger = 4096;                // see reserve_particles
+constexpr uint32_t kFoldBlocks = 64;                 // first-level blocks of the diagnostics fold
 
 }  // namespace
 
@@ -71,6 +73,7 @@ struct pcl_compute {
 
     size_t n = 0;
     size_t capacity = 0;
+    char* slab = nullptr;              // one allocation holding every particle array
     float* state[2][6] = {{nullptr}};
     uint8_t* ty = nullptr;
     int cur = 0;
@@ -108,25 +111,30 @@ int bind(const pcl_compute* h)
 
 void free_particles(pcl_compute* h)
 {
+    if (h->slab) (void)hipFree(h->slab);
+    h->slab = nullptr;
     for (int b = 0; b < 2; ++b)
-        for (int a = 0; a < 6; ++a) {
-            if (h->state[b][a]) (void)hipFree(h->state[b][a]);
-            h->state[b][a] = nullptr;
-        }
-    if (h->ty) (void)hipFree(h->ty);
+        for (int a = 0; a < 6; ++a) h->state[b][a] = nullptr;
     h->ty = nullptr;
     h->capacity = 0;
 }
 
+// The 13 particle arrays live in one allocation.  Array k starts at
+// k * (round_up(4n, 2 MiB) + 2 MiB + 4 KiB): the 4 KiB stagger keeps the 13
+// concurrent streams of a wave off the same HBM channel (all-equal low address
+// bits cost up to 15 % of the streaming rate).
 int reserve_particles(pcl_compute* h, size_t n)
 {
     if (n <= h->capacity) return PCL_OK;
     // All work queued on the old arrays must finish before they are freed.
     PCL_HIP_TRY(hipStreamSynchronize(h->stream));
     free_particles(h);
+    constexpr size_t kTwoMiB = size_t(2) << 20;
+    const size_t stride = (n * sizeof(float) + kTwoMiB - 1) / kTwoMiB * kTwoMiB + kTwoMiB + kArrayStagger;
+    PCL_HIP_TRY(hipMalloc((void**)&h->slab, 13 * stride));
     for (int b = 0; b < 2; ++b)
-        for (int a = 0; a < 6; ++a) PCL_HIP_TRY(hipMalloc((void**)&h->state[b][a], n * sizeof(float)));
-    PCL_HIP_TRY(hipMalloc((void**)&h->ty, n));
+        for (int a = 0; a < 6; ++a) h->state[b][a] = reinterpret_cast<float*>(h->slab + (size_t)(b * 6 + a) * stride);
+    h->ty = reinterpret_cast<uint8_t*>(h->slab + 12 * stride);
     h->capacity = n;
     return PCL_OK;
 }
@@ -151,7 +159,7 @@ int reserve_partials(pcl_compute* h, size_t blocks)
     h->d_partials = nullptr;
     h->partials_capacity = 0;
     const size_t cap = std::max<size_t>(blocks, 4096);
-    PCL_HIP_TRY(hipMalloc((void**)&h->d_partials, cap * sizeof(pcl::DiagPartial)));
+    PCL_HIP_TRY(hipMalloc((void**)&h->d_partials, (cap + kFoldBlocks) * sizeof(pcl::DiagPartial)));
     h->partials_capacity = cap;
     return PCL_OK;
 }
@@ -199,16 +207,29 @@ bool pair_term_inert(const pcl_sim_params& p)
     return true;
 }
 
-uint32_t default_grid_cap(const pcl_compute* h)
-{
-    return h->grid_cap ? h->grid_cap : (uint32_t)h->num_cus * 8u;
-}
-
-uint32_t stream_grid(const pcl_compute* h, size_t n)
+size_t stream_tiles(size_t n)
 {
     const size_t groups = n / 4;
-    const size_t blocks = (groups + pcl::kBlockThreads - 1) / pcl::kBlockThreads;
-    return (uint32_t)std::max<size_t>(1, std::min<size_t>(blocks, default_grid_cap(h)));
+    return std::max<size_t>(1, (groups + pcl::kStreamThreads - 1) / pcl::kStreamThreads);
+}
+
+// Small field and enough tiles per persistent block to amortise the copy:
+// stage the field in LDS (variant bit 1 disables it).
+bool use_lds_field(const pcl_compute* h)
+{
+    const size_t field_bytes = h->n_cells * sizeof(pcl::f32x4);
+    const size_t persistent = (size_t)h->num_cus * 2;
+    return field_bytes <= kLdsFieldMaxBytes && (h->variant & 2u) == 0 && stream_tiles(h->n) >= persistent * 4;
+}
+
+// One tile per block, or (LDS-staged field, or an explicit cap) a persistent
+// grid that strides over the tiles.
+uint32_t stream_grid(const pcl_compute* h)
+{
+    size_t blocks = stream_tiles(h->n);
+    if (h->grid_cap) blocks = std::min<size_t>(blocks, h->grid_cap);
+    else if (use_lds_field(h)) blocks = std::min<size_t>(blocks, (size_t)h->num_cus * 2);
+    return (uint32_t)std::min<size_t>(blocks, 0x7FFFFFFFu);
 }
 
 uint32_t linear_grid(const pcl_compute* h, size_t count)
@@ -217,10 +238,23 @@ uint32_t linear_grid(const pcl_compute* h, size_t count)
     return (uint32_t)std::max<size_t>(1, std::min<size_t>(blocks, (size_t)h->num_cus * 16u));
 }
 
+// Two-level fold of the first n_partials entries of d_partials (the second
+// level lives in the 64 entries past partials_capacity).
 int launch_finalize(pcl_compute* h, uint32_t n_partials, pcl::DiagOut* dev_out)
 {
-    hipLaunchKernelGGL(pcl::diag_finalize_kernel, dim3(1), dim3(pcl::kBlockThreads), 0, h->stream,
-                       h->d_partials, n_partials, dev_out);
+    const pcl::DiagPartial* in = h->d_partials;
+    if (n_partials > 4096u) {
+        pcl::DiagPartial* level2 = h->d_partials + h->partials_capacity;
+        const uint32_t chunk = (n_partials + kFoldBlocks - 1) / kFoldBlocks;
+        const uint32_t blocks = (n_partials + chunk - 1) / chunk;
+        hipLaunchKernelGGL(pcl::diag_fold_kernel, dim3(blocks), dim3(pcl::kBlockThreads), 0, h->stream,
+                           in, n_partials, chunk, level2, (pcl::DiagOut*)nullptr);
+        PCL_HIP_TRY(hipGetLastError());
+        in = level2;
+        n_partials = blocks;
+    }
+    hipLaunchKernelGGL(pcl::diag_fold_kernel, dim3(1), dim3(pcl::kBlockThreads), 0, h->stream,
+                       in, n_partials, n_partials, (pcl::DiagPartial*)nullptr, dev_out);
     PCL_HIP_TRY(hipGetLastError());
     return PCL_OK;
 }
@@ -232,10 +266,10 @@ int launch_stream(pcl_compute* h, const pcl::StreamArgs& a, const pcl::StepUnifo
     if (lds) {
         const size_t bytes = (size_t)a.lds_cells * sizeof(pcl::f32x4);
         hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, true>), dim3(grid),
-                           dim3(pcl::kBlockThreads), bytes, h->stream, a, U);
+                           dim3(pcl::kStreamThreads), bytes, h->stream, a, U);
     } else {
         hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, false>), dim3(grid),
-                           dim3(pcl::kBlockThreads), 0, h->stream, a, U);
+                           dim3(pcl::kStreamThreads), 0, h->stream, a, U);
     }
     PCL_HIP_TRY(hipGetLastError());
     return PCL_OK;
@@ -259,7 +293,7 @@ int do_step(pcl_compute* h)
     uint32_t grid = 0;
 
     if (!use_pairs) {
-        grid = stream_grid(h, h->n);
+        grid = stream_grid(h);
         if (h->step_diag)
             if (int rc = reserve_partials(h, grid)) return rc;
         pcl::StreamArgs a;
@@ -268,11 +302,7 @@ int do_step(pcl_compute* h)
         a.field = h->field;
         a.n = h->n;
         a.partials = h->d_partials;
-        // Stage the field in LDS when it is small and every persistent block
-        // amortises the copy over at least a few tiles.
-        const size_t field_bytes = h->n_cells * sizeof(pcl::f32x4);
-        const bool lds = field_bytes <= kLdsFieldMaxBytes && (h->variant & 2u) == 0 &&
-                         h->n >= (size_t)grid * pcl::kTileParticles * 4;
+        const bool lds = use_lds_field(h);
         a.lds_cells = lds ? (uint32_t)h->n_cells : 0u;
         const bool nt = (h->variant & 1u) == 0;
         int rc;
@@ -719,8 +749,8 @@ int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks, uint32_t* b
                         uint32_t* particles_per_lane)
 {
     if (!h) return fail(PCL_ERR_INVALID, "null handle");
-    if (grid_blocks) *grid_blocks = stream_grid(h, h->n);
-    if (block_threads) *block_threads = pcl::kBlockThreads;
+    if (grid_blocks) *grid_blocks = stream_grid(h);
+    if (block_threads) *block_threads = pcl::kStreamThreads;
     if (particles_per_lane) *particles_per_lane = pcl::kParticlesPerLane;
     return PCL_OK;
 }

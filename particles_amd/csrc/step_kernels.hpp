@@ -113,7 +113,7 @@ __device__ __forceinline__ void integrate(const StepUniforms& U, float fx, float
     vy = vy + ay * U.dt;
     vz = vz + az * U.dt;
 
-    const float vel = __fsqrt_rn((vx * vx + vy * vy) + vz * vz);
+    const float vel = sqrtf((vx * vx + vy * vy) + vz * vz);
     if (vel > 0.001f) {
         const float capped = fminf(fmaxf(vel, 0.0f), U.max_velocity);
         vx = __fdiv_rn(vx, vel) * capped;
@@ -173,9 +173,10 @@ __device__ __forceinline__ unsigned long long shfl_down_u64(unsigned long long v
 // Reduce one accumulator per thread to one DiagPartial per block, in a fixed
 // order (wave tree, then waves 0..3 in sequence): deterministic for a given
 // launch geometry.
+template <int THREADS = kBlockThreads>
 __device__ __forceinline__ void block_reduce_store(DiagAcc acc, DiagPartial* out)
 {
-    __shared__ DiagPartial wave_part[kBlockThreads / 64];
+    __shared__ DiagPartial wave_part[THREADS / 64];
     for (int d = 32; d >= 1; d >>= 1) {
         acc.ke += shfl_down_f64(acc.ke, d);
         acc.count += shfl_down_u64(acc.count, d);
@@ -196,7 +197,7 @@ __device__ __forceinline__ void block_reduce_store(DiagAcc acc, DiagPartial* out
     __syncthreads();
     if (threadIdx.x == 0) {
         DiagPartial p = wave_part[0];
-        for (int w = 1; w < kBlockThreads / 64; ++w) {
+        for (int w = 1; w < THREADS / 64; ++w) {
             p.kinetic_energy += wave_part[w].kinetic_energy;
             p.count += wave_part[w].count;
             for (int c = 0; c < 3; ++c) {
@@ -217,15 +218,19 @@ struct DiagOut {
     float pad[2];
 };
 
-// One block: fold `n_partials` block partials, in index order per thread and
-// then through the same fixed tree.
-__global__ __launch_bounds__(kBlockThreads) void diag_finalize_kernel(
-    const DiagPartial* __restrict__ partials, uint32_t n_partials, DiagOut* __restrict__ out)
+// Fold block partials in a fixed order: block b of the grid folds the
+// contiguous chunk [b*chunk, (b+1)*chunk) into out_partials[b]; the last level
+// (one block) also writes the pcl_diagnostics record.
+__global__ __launch_bounds__(kBlockThreads) void diag_fold_kernel(
+    const DiagPartial* __restrict__ partials, uint32_t n_partials, uint32_t chunk,
+    DiagPartial* __restrict__ out_partials, DiagOut* __restrict__ out)
 {
     __shared__ DiagPartial folded;
     DiagAcc acc;
     acc.init();
-    for (uint32_t i = threadIdx.x; i < n_partials; i += kBlockThreads) {
+    const uint32_t begin = blockIdx.x * chunk;
+    const uint32_t end = begin + chunk < n_partials ? begin + chunk : n_partials;
+    for (uint32_t i = begin + threadIdx.x; i < end; i += kBlockThreads) {
         const DiagPartial p = partials[i];
         acc.ke += p.kinetic_energy;
         acc.count += p.count;
@@ -237,12 +242,15 @@ __global__ __launch_bounds__(kBlockThreads) void diag_finalize_kernel(
     block_reduce_store(acc, &folded);
     __syncthreads();
     if (threadIdx.x == 0) {
-        DiagOut o;
-        o.count = (double)folded.count;
-        o.kinetic_energy = folded.kinetic_energy;
-        for (int c = 0; c < 3; ++c) { o.pos_max[c] = folded.pos_max[c]; o.neg_pos_min[c] = folded.neg_pos_min[c]; }
-        o.pad[0] = o.pad[1] = 0.0f;
-        *out = o;
+        if (out_partials) out_partials[blockIdx.x] = folded;
+        if (out) {
+            DiagOut o;
+            o.count = (double)folded.count;
+            o.kinetic_energy = folded.kinetic_energy;
+            for (int c = 0; c < 3; ++c) { o.pos_max[c] = folded.pos_max[c]; o.neg_pos_min[c] = folded.neg_pos_min[c]; }
+            o.pad[0] = o.pad[1] = 0.0f;
+            *out = o;
+        }
     }
 }
 
@@ -277,16 +285,21 @@ __device__ __forceinline__ void store4(float* base, unsigned long long group, f3
 // Pair term provably zero (every polynomial coefficient +-0, or no distance
 // can pass both cut-offs): wgsl:115-144 contributes exactly +0, so the update
 // is a pure stream: 24 B state + 1 B type in, 24 B out per particle, plus one
-// cache-resident 16-byte field fetch.  Persistent grid, grid-stride over
-// groups of 4 consecutive particles per lane.
+// cache-resident 16-byte field fetch.  A block owns tiles of kStreamThreads*4
+// consecutive particles (one 16-byte access per array per lane); the grid is
+// one tile per block, or a smaller persistent grid striding over the tiles
+// when the field is staged in LDS.
+constexpr int kStreamThreads = 512;  // 8 waves
+constexpr int kStreamTile = kStreamThreads * kParticlesPerLane;
+
 template <bool DIAG, bool NT, bool FIELD_LDS>
-__global__ __launch_bounds__(kBlockThreads) void step_stream_kernel(StreamArgs a, StepUniforms U)
+__global__ __launch_bounds__(kStreamThreads) void step_stream_kernel(StreamArgs a, StepUniforms U)
 {
     // Small fields (<= 64 KiB) are staged in LDS once per persistent block;
     // larger ones are fetched through L2 / Infinity Cache.
     extern __shared__ __attribute__((aligned(16))) f32x4 lds_field[];
     if (FIELD_LDS) {
-        for (uint32_t c = threadIdx.x; c < a.lds_cells; c += kBlockThreads) lds_field[c] = a.field[c];
+        for (uint32_t c = threadIdx.x; c < a.lds_cells; c += kStreamThreads) lds_field[c] = a.field[c];
         __syncthreads();
     }
     auto fetch = [&](uint32_t c) -> f32x4 { return FIELD_LDS ? lds_field[c] : a.field[c]; };
@@ -295,9 +308,10 @@ __global__ __launch_bounds__(kBlockThreads) void step_stream_kernel(StreamArgs a
     if (DIAG) acc.init();
 
     const unsigned long long n_groups = a.n / 4ull;
-    const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
-    for (unsigned long long g = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x;
-         g < n_groups; g += stride) {
+    const unsigned long long n_tiles = (n_groups + kStreamThreads - 1) / kStreamThreads;
+    for (unsigned long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const unsigned long long g = t * kStreamThreads + threadIdx.x;
+        if (g >= n_groups) break;
         f32x4 X = load4<NT>(a.src[0], g);
         f32x4 Y = load4<NT>(a.src[1], g);
         f32x4 Z = load4<NT>(a.src[2], g);
@@ -307,12 +321,9 @@ __global__ __launch_bounds__(kBlockThreads) void step_stream_kernel(StreamArgs a
         const uint32_t t4 = NT ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.ty) + g)
                                : reinterpret_cast<const uint32_t*>(a.ty)[g];
 
-        uint32_t cell[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) cell[k] = cell_index(U, X[k], Y[k], Z[k]);
         f32x4 F[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) F[k] = fetch(cell[k]);
+        for (int k = 0; k < 4; ++k) F[k] = fetch(cell_index(U, X[k], Y[k], Z[k]));
 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -344,7 +355,7 @@ __global__ __launch_bounds__(kBlockThreads) void step_stream_kernel(StreamArgs a
         if (DIAG) acc.add(m, x, y, z, vx, vy, vz);
     }
 
-    if (DIAG) block_reduce_store(acc, a.partials + blockIdx.x);
+    if (DIAG) block_reduce_store<kStreamThreads>(acc, a.partials + blockIdx.x);
 }
 
 // -------------------------------------------------------- general kernel K2
@@ -427,7 +438,7 @@ __global__ __launch_bounds__(kBlockThreads) void step_pairs_kernel(PairArgs a, S
                 if (base + jj == i) continue;                       // wgsl:120-122
                 const f32x4 o = tile[jj];
                 const float dx = o.x - x, dy = o.y - y, dz = o.z - z;
-                const float len = __fsqrt_rn((dx * dx + dy * dy) + dz * dz);
+                const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
                 if (len < 0.001f) continue;                         // wgsl:126-128
                 if (len > cut_off) continue;                        // wgsl:129-131
                 // pow(x, 0) is exactly 1 for every finite positive x

@@ -1,0 +1,308 @@
+// kbench.hip — standalone timing harness for variants of the streaming kernel
+// (development tool; not part of the library).  Build:
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -Iinclude -Iparticles_amd/csrc tools/kbench.hip -o tools/kbench
+// Run on the GPU box: tools/kbench [log2n] [field_side] [pos_extent]
+#include "step_kernels.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+using namespace pcl;
+
+// G = float4 groups per lane per array (particles per lane = 4*G)
+// GPOL: cache-policy bits of the field fetch (buffer_load aux: 1 = sc0, 2 = nt, 16 = sc1); -1 = plain global_load
+template <int G, bool NT_LD, bool NT_ST, bool PERSIST, bool GATHER, int BLOCK, int GPOL = -1>
+__global__ __launch_bounds__(BLOCK) void variant_kernel(StreamArgs a, StepUniforms U)
+{
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<f32x4*>(a.field), 0, (U.last_cell + 1u) * 16u, 0x00020000);
+    const unsigned long long n_groups = a.n / 4ull;  // n is a multiple of 4*G*BLOCK here
+    const unsigned long long tile = (unsigned long long)BLOCK * G;
+    const unsigned long long n_tiles = n_groups / tile;
+    for (unsigned long long t = blockIdx.x; t < n_tiles; t += PERSIST ? gridDim.x : n_tiles) {
+        f32x4 X[G], Y[G], Z[G], VX[G], VY[G], VZ[G];
+        uint32_t T[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const unsigned long long g = t * tile + (unsigned long long)j * BLOCK + threadIdx.x;
+            X[j] = load4<NT_LD>(a.src[0], g);
+            Y[j] = load4<NT_LD>(a.src[1], g);
+            Z[j] = load4<NT_LD>(a.src[2], g);
+            VX[j] = load4<NT_LD>(a.src[3], g);
+            VY[j] = load4<NT_LD>(a.src[4], g);
+            VZ[j] = load4<NT_LD>(a.src[5], g);
+            T[j] = NT_LD ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.ty) + g)
+                         : reinterpret_cast<const uint32_t*>(a.ty)[g];
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            f32x4 F[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t c = cell_index(U, X[j][k], Y[j][k], Z[j][k]);
+                const uint32_t cc = GATHER ? c : (c & 63u);
+                if (GPOL < 0) F[k] = a.field[cc];
+                else {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cc * 16u), 0, GPOL < 0 ? 0 : GPOL);
+                    F[k] = __builtin_bit_cast(f32x4, raw);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float m = mass_of(U, (T[j] >> (8 * k)) & 0xFFu);
+                float x = X[j][k], y = Y[j][k], z = Z[j][k], vx = VX[j][k], vy = VY[j][k], vz = VZ[j][k];
+                integrate(U, F[k].x, F[k].y, F[k].z, m, 0.0f, 0.0f, 0.0f, x, y, z, vx, vy, vz);
+                X[j][k] = x; Y[j][k] = y; Z[j][k] = z; VX[j][k] = vx; VY[j][k] = vy; VZ[j][k] = vz;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const unsigned long long g = t * tile + (unsigned long long)j * BLOCK + threadIdx.x;
+            store4<NT_ST>(a.dst[0], g, X[j]);
+            store4<NT_ST>(a.dst[1], g, Y[j]);
+            store4<NT_ST>(a.dst[2], g, Z[j]);
+            store4<NT_ST>(a.dst[3], g, VX[j]);
+            store4<NT_ST>(a.dst[4], g, VY[j]);
+            store4<NT_ST>(a.dst[5], g, VZ[j]);
+        }
+    }
+}
+
+// Pure copy of the same byte mix (6 arrays in, 6 out, 1 B type in): the stream's ceiling.
+template <bool NT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void copy_kernel(StreamArgs a)
+{
+    const unsigned long long g = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= a.n / 4ull) return;
+    f32x4 v[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = load4<NT>(a.src[k], g);
+    const uint32_t t = reinterpret_cast<const uint32_t*>(a.ty)[g];
+    v[0].x += __uint_as_float(t & 1u);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) store4<NT>(a.dst[k], g, v[k]);
+}
+
+// Plain float4 copy a -> b
+template <bool NT>
+__global__ __launch_bounds__(256) void copy1_kernel(const f32x4* __restrict__ s, f32x4* __restrict__ d, unsigned long long n4)
+{
+    const unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (g < n4) {
+        f32x4 v = NT ? __builtin_nontemporal_load(s + g) : s[g];
+        if (NT) __builtin_nontemporal_store(v, d + g); else d[g] = v;
+    }
+}
+
+// Particles whose memory order follows the field's tile order: particle i sits
+// uniformly inside tile (i * n_tiles / n) of tile_cells x tile_cells cells,
+// tiles enumerated x-major (emulates a cell-sorted particle set).
+__global__ void generate_sorted_kernel(StateSoA s, uint8_t* ty, unsigned long long n, unsigned side, unsigned tile_cells, float radius)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    const unsigned tiles_per_side = side / tile_cells;
+    const unsigned long long n_tiles = (unsigned long long)tiles_per_side * tiles_per_side;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned long long t = (unsigned long long)((__uint128_t)i * n_tiles / n);
+        const unsigned tx = (unsigned)(t / tiles_per_side), tyy = (unsigned)(t % tiles_per_side);
+        const float w = 2.0f * radius / (float)tiles_per_side;
+        s.a[0][i] = -radius + w * ((float)tx + synth_uniform(1, i, 0));
+        s.a[1][i] = -radius + w * ((float)tyy + synth_uniform(1, i, 1));
+        s.a[2][i] = 2.0f * radius * (synth_uniform(1, i, 2) - 0.5f);
+        for (int c = 0; c < 3; ++c) s.a[3 + c][i] = 10.0f * (synth_uniform(1, i, 3 + c) - 0.5f);
+        ty[i] = (uint8_t)(i % 5ull);
+    }
+}
+
+struct Ctx {
+    unsigned long long n;
+    StreamArgs fwd, bwd;
+    StepUniforms U;
+    hipEvent_t e0, e1;
+    StateSoA s0;
+    uint8_t* ty;
+    float extent;
+    void regen()
+    {
+        hipLaunchKernelGGL(generate_kernel, dim3(4096), dim3(256), 0, 0, s0, ty, n, 12345ull, 0ull, extent, 10.0f);
+        CK(hipDeviceSynchronize());
+    }
+};
+
+template <typename F>
+static float time_ms(Ctx& c, F launch, int reps = 20)
+{
+    for (int i = 0; i < 3; ++i) launch(i & 1 ? c.bwd : c.fwd);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(c.e0));
+    for (int i = 0; i < reps; ++i) launch(i & 1 ? c.bwd : c.fwd);
+    CK(hipEventRecord(c.e1));
+    CK(hipEventSynchronize(c.e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, c.e0, c.e1));
+    CK(hipGetLastError());
+    return ms / reps;
+}
+
+static void report(const char* name, Ctx& c, float ms, double bytes_per_particle = 49.0)
+{
+    printf("%-58s %8.4f ms  %8.1f GB/s  %7.2f Gp/s\n", name, ms, c.n * bytes_per_particle / ms / 1e6, c.n / ms / 1e6);
+    fflush(stdout);
+}
+
+template <int G, bool NT_LD, bool NT_ST, bool PERSIST, bool GATHER, int BLOCK, int GPOL = -1>
+static void run_variant(Ctx& c, const char* label, int blocks_per_cu = 8)
+{
+    c.regen();
+    const unsigned long long n_tiles = c.n / 4ull / ((unsigned long long)BLOCK * G);
+    const unsigned grid = PERSIST ? (unsigned)std::min<unsigned long long>(n_tiles, 256ull * blocks_per_cu) : (unsigned)n_tiles;
+    float ms = time_ms(c, [&](StreamArgs& a) {
+        hipLaunchKernelGGL((variant_kernel<G, NT_LD, NT_ST, PERSIST, GATHER, BLOCK, GPOL>), dim3(grid), dim3(BLOCK), 0, 0, a, c.U);
+    });
+    char name[128];
+    snprintf(name, sizeof name, "%s G=%d ntld=%d ntst=%d persist=%d(%u) gather=%d block=%d gpol=%d", label, G, NT_LD, NT_ST, PERSIST, grid, GATHER, BLOCK, GPOL);
+    report(name, c, ms);
+}
+
+int main(int argc, char** argv)
+{
+    const int log2n = argc > 1 ? atoi(argv[1]) : 26;
+    const unsigned side = argc > 2 ? atoi(argv[2]) : 1024;
+    const float extent = argc > 3 ? atof(argv[3]) : 20.0f;
+    const size_t stagger = argc > 4 ? atol(argv[4]) : 0;  // bytes between consecutive array bases (mod 2 MiB)
+    Ctx c;
+    c.n = 1ull << log2n;
+    CK(hipEventCreate(&c.e0));
+    CK(hipEventCreate(&c.e1));
+    const size_t n_cells = (size_t)side * side;
+
+    // one slab, arrays optionally staggered
+    const size_t arr_bytes = c.n * 4 + (2u << 20);
+    char* slab = nullptr;
+    CK(hipMalloc((void**)&slab, arr_bytes * 12 + c.n + (64u << 20)));
+    float* st[2][6];
+    for (int b = 0; b < 2; ++b)
+        for (int k = 0; k < 6; ++k) st[b][k] = (float*)(slab + (size_t)(b * 6 + k) * arr_bytes + (size_t)(b * 6 + k) * stagger);
+    uint8_t* ty = (uint8_t*)(slab + 12 * arr_bytes + 12 * stagger);
+    f32x4* field = nullptr;
+    CK(hipMalloc((void**)&field, n_cells * 16));
+    std::vector<float> hf(n_cells * 4);
+    for (size_t i = 0; i < hf.size(); ++i) hf[i] = (float)((i * 2654435761u) >> 8 & 0xFFFF) / 65536.0f - 0.5f;
+    CK(hipMemcpy(field, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
+
+    for (int k = 0; k < 6; ++k) c.s0.a[k] = st[0][k];
+    c.ty = ty;
+    c.extent = extent;
+    c.regen();
+
+    for (int k = 0; k < 6; ++k) {
+        c.fwd.src[k] = st[0][k]; c.fwd.dst[k] = st[1][k];
+        c.bwd.src[k] = st[1][k]; c.bwd.dst[k] = st[0][k];
+    }
+    c.fwd.ty = c.bwd.ty = ty;
+    c.fwd.field = c.bwd.field = field;
+    c.fwd.n = c.bwd.n = c.n;
+    c.fwd.partials = c.bwd.partials = nullptr;
+    c.fwd.lds_cells = c.bwd.lds_cells = 0;
+
+    StepUniforms& U = c.U;
+    const float r = 10.0f, dt = 1.0f / 60.0f;
+    U.decay = expf(-dt); U.dt = dt; U.max_velocity = 100.0f; U.radius = r; U.two_radius = 2.0f * r;
+    U.slh = (r * 2.0f) * 0.5f; U.neg_slh = -U.slh; U.span_a = U.slh - U.neg_slh;
+    U.span_b[0] = (float)side; U.span_b[1] = (float)side; U.span_b[2] = 1.0f;
+    U.dim_y = side; U.dim_z = 1; U.last_cell = (uint32_t)(n_cells - 1); U.degenerate = 0;
+    const float masses[5] = {1.0f, 0.5f, 2.0f, 1.5f, 0.75f};
+    for (int k = 0; k < 5; ++k) U.mass[k] = masses[k];
+
+    printf("n=2^%d field=%u^2 extent=%.1f stagger=%zu\n", log2n, side, extent, stagger);
+
+    // ceilings
+    {
+        const unsigned long long n4 = c.n;  // copy n*16 bytes: use 4 arrays' worth
+        float ms = time_ms(c, [&](StreamArgs& a) {
+            hipLaunchKernelGGL(copy1_kernel<false>, dim3((unsigned)((n4 / 4 + 255) / 256)), dim3(256), 0, 0,
+                               (const f32x4*)a.src[0], (f32x4*)a.dst[0], n4 / 4);
+        });
+        report("float4 copy (1 array, plain)", c, ms, 8.0);
+        ms = time_ms(c, [&](StreamArgs& a) {
+            hipLaunchKernelGGL(copy1_kernel<true>, dim3((unsigned)((n4 / 4 + 255) / 256)), dim3(256), 0, 0,
+                               (const f32x4*)a.src[0], (f32x4*)a.dst[0], n4 / 4);
+        });
+        report("float4 copy (1 array, nt)", c, ms, 8.0);
+        ms = time_ms(c, [&](StreamArgs& a) {
+            hipLaunchKernelGGL((copy_kernel<false, 256>), dim3((unsigned)(c.n / 4 / 256)), dim3(256), 0, 0, a);
+        });
+        report("13-stream copy (plain)", c, ms);
+        ms = time_ms(c, [&](StreamArgs& a) {
+            hipLaunchKernelGGL((copy_kernel<true, 256>), dim3((unsigned)(c.n / 4 / 256)), dim3(256), 0, 0, a);
+        });
+        report("13-stream copy (nt)", c, ms);
+    }
+
+    const int set = argc > 5 ? atoi(argv[5]) : 0;
+    if (set == 0) {
+        run_variant<1, true, true, false, true, 256>(c, "step");
+        run_variant<1, true, true, false, false, 256>(c, "step");
+        run_variant<1, true, true, false, true, 512>(c, "step");
+        run_variant<1, true, true, false, false, 512>(c, "step");
+        run_variant<1, true, true, false, true, 1024>(c, "step");
+        run_variant<2, true, true, false, true, 256>(c, "step");
+        run_variant<2, true, true, false, true, 512>(c, "step");
+        run_variant<1, true, true, true, true, 256>(c, "step");
+        run_variant<1, true, true, true, true, 512>(c, "step", 4);
+    } else if (set == 1) {
+        run_variant<1, true, true, false, true, 256, -1>(c, "step");
+        run_variant<1, true, true, false, true, 256, 0>(c, "step");
+        run_variant<1, true, true, false, true, 256, 1>(c, "step");
+        run_variant<1, true, true, false, true, 256, 2>(c, "step");
+        run_variant<1, true, true, false, true, 256, 16>(c, "step");
+        run_variant<1, true, true, false, true, 256, 17>(c, "step");
+        run_variant<1, true, true, false, true, 256, 18>(c, "step");
+        run_variant<1, true, true, false, true, 256, 19>(c, "step");
+        run_variant<1, true, true, false, true, 512, 0>(c, "step");
+        run_variant<1, true, true, false, true, 512, 2>(c, "step");
+        run_variant<1, true, true, false, true, 512, 16>(c, "step");
+        run_variant<1, true, true, false, true, 512, 17>(c, "step");
+    }
+    if (set == 3) {
+        // stagger sweep on the stream alone (field fetch confined to 1 KiB) and with the fetch
+        const size_t staggers[] = {0, 256, 512, 1024, 2048, 4096, 4352, 8192, 8448, 16640, 33024, 65792, 131328, 262400, 1048832, 69888, 135424};
+        for (size_t sg : staggers) {
+            for (int b = 0; b < 2; ++b)
+                for (int k = 0; k < 6; ++k) st[b][k] = (float*)(slab + (size_t)(b * 6 + k) * arr_bytes + (size_t)(b * 6 + k) * sg);
+            ty = (uint8_t*)(slab + 12 * arr_bytes + 12 * sg);
+            for (int k = 0; k < 6; ++k) {
+                c.s0.a[k] = st[0][k];
+                c.fwd.src[k] = st[0][k]; c.fwd.dst[k] = st[1][k];
+                c.bwd.src[k] = st[1][k]; c.bwd.dst[k] = st[0][k];
+            }
+            c.ty = ty; c.fwd.ty = ty; c.bwd.ty = ty;
+            printf("stagger %zu\n", sg);
+            run_variant<1, true, true, false, false, 256>(c, "  step");
+            run_variant<1, true, true, false, true, 512>(c, "  step");
+        }
+    }
+    if (set == 2) {
+        const unsigned tile_cells = argc > 6 ? atoi(argv[6]) : 16;
+        hipLaunchKernelGGL(generate_sorted_kernel, dim3(4096), dim3(256), 0, 0, c.s0, c.ty, c.n, side, tile_cells, r);
+        CK(hipDeviceSynchronize());
+        const unsigned grid = (unsigned)(c.n / 4ull / 256ull);
+        printf("sorted by %ux%u-cell tiles; per-step time as the order decays\n", tile_cells, tile_cells);
+        for (int k = 0; k < 129; ++k) {
+            StreamArgs& a = (k & 1) ? c.bwd : c.fwd;
+            CK(hipEventRecord(c.e0));
+            hipLaunchKernelGGL((variant_kernel<1, true, true, false, true, 256, -1>), dim3(grid), dim3(256), 0, 0, a, c.U);
+            CK(hipEventRecord(c.e1));
+            CK(hipEventSynchronize(c.e1));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, c.e0, c.e1));
+            if (k < 4 || (k & (k - 1)) == 0 || k % 16 == 0) printf("step %3d: %8.4f ms  %8.1f GB/s %7.2f Gp/s\n", k, ms, c.n * 49.0 / ms / 1e6, c.n / ms / 1e6);
+        }
+    }
+    return 0;
+}
