@@ -1,0 +1,231 @@
+"""Particle-sharded update over the GPUs of one node (one process per GPU).
+
+With the pair term inert every particle depends only on its own state, the
+replicated field and the replicated 912-byte parameter block, so the particle
+set is split into contiguous index ranges, one per rank, with no data-path
+collective.  What does travel, over ``torch.distributed`` (backend "nccl" is
+RCCL over xGMI on ROCm):
+
+* the field — built on rank 0, replicated with one broadcast at construction,
+  after ``update_force_grid`` and (dirty range only) after ``patch_force_grid``
+  (the reference re-uploads the whole field every frame: src/main.rs:371-380);
+* per-step diagnostics — two tiny all-reduces (sum: count, kinetic energy;
+  max: max xyz, -min xyz), issued asynchronously so they overlap the next step.
+
+The class mirrors ``Compute`` (src/compute.rs:11-228); ``compute_cls`` is the
+single-GPU backend each rank instantiates for its range.
+"""
+import numpy as np
+
+from .compute import Compute
+from .particle import PARTICLE_DTYPE
+
+
+def shard_range(n_total, rank, world_size):
+    """Contiguous index range [first, last) owned by ``rank``: g*N/G .. (g+1)*N/G."""
+    first = (rank * n_total) // world_size
+    last = ((rank + 1) * n_total) // world_size
+    return first, last
+
+
+class ShardedCompute:
+    def __init__(self, particles, force_grid, *, process_group=None, device=None, compute_cls=Compute,
+                 n_total=None, seed=None, pos_extent=2.0, vel_extent=10.0):
+        """Every rank passes the full ``particles`` array and keeps its own
+        range, or passes ``particles=None`` with ``n_total`` and ``seed`` to
+        fill its range with the seeded synthetic scene on the device.
+        ``force_grid`` is taken from rank 0 (other ranks may pass ``None``).
+        """
+        import torch
+        import torch.distributed as dist
+
+        self._torch, self._dist = torch, dist
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
+        self.on_gpu = backend == "nccl" or (backend == "none" and torch.cuda.is_available())
+        if device is None:
+            device = torch.cuda.current_device() if self.on_gpu else 0
+        self.device = int(device)
+        self._comm_device = torch.device("cuda", self.device) if self.on_gpu else torch.device("cpu")
+
+        if particles is not None:
+            particles = np.ascontiguousarray(particles).reshape(-1)
+            self.n_total = particles.shape[0]
+        else:
+            if n_total is None or seed is None:
+                raise ValueError("pass either particles, or n_total and seed")
+            self.n_total = int(n_total)
+        self.first, self.last = shard_range(self.n_total, self.rank, self.world_size)
+
+        grid = self._replicate_field(force_grid, 0, None)
+        local = particles[self.first:self.last] if particles is not None else np.zeros(0, dtype=PARTICLE_DTYPE)
+        if self.on_gpu and self.world_size > 1:
+            # the replicated field is already on this device: adopt it without a host round trip
+            self.local = compute_cls.new(local, np.zeros((1, 4), dtype=np.float32), device=self.device)
+            self.local.set_stream(torch.cuda.current_stream().cuda_stream)
+            self.local.update_force_grid_device(grid.data_ptr(), grid.shape[0])
+        else:
+            self.local = compute_cls.new(local, grid, device=self.device)
+            if self.on_gpu:
+                self.local.set_stream(torch.cuda.current_stream().cuda_stream)
+        if particles is None:
+            self.local.generate_particles(self.last - self.first, seed, first_global_index=self.first,
+                                          pos_extent=pos_extent, vel_extent=vel_extent)
+        self._diag_enabled = False
+        # Ring of diagnostics records: an all-reduce in flight owns its record
+        # until waited for, so consecutive steps use different ones.
+        self._diag_ring = None
+        self._diag_slot = 0
+        self._pending = []
+
+    @classmethod
+    def new(cls, particles, force_grid, **kw):
+        return cls(particles, force_grid, **kw)
+
+    # -- field replication ------------------------------------------------
+    def _replicate_field(self, cells, first_cell, count):
+        """Broadcast rank 0's cells [first_cell, first_cell+count) (count=None:
+        the whole array) and return them as a host array on every rank."""
+        torch, dist = self._torch, self._dist
+        if self.world_size == 1:
+            return np.ascontiguousarray(cells, dtype=np.float32)
+        header = [None]
+        if self.rank == 0:
+            cells = np.ascontiguousarray(cells, dtype=np.float32)
+            header = [(int(first_cell), int(cells.shape[0]))]
+        dist.broadcast_object_list(header, src=0, group=self.group)
+        first_cell, n = header[0]
+        t = torch.empty((n, 4), dtype=torch.float32, device=self._comm_device)
+        if self.rank == 0:
+            t.copy_(torch.from_numpy(cells))
+        dist.broadcast(t, src=0, group=self.group)
+        self._last_field_tensor = t          # keeps the device buffer alive for *_device uploads
+        self._last_first_cell = first_cell
+        return t.cpu().numpy() if not self.on_gpu else t
+
+    def update_force_grid(self, force_grid):
+        """Whole-field replace (src/compute.rs:198-204) from rank 0's array."""
+        g = self._replicate_field(force_grid, 0, None)
+        if self.on_gpu and self.world_size > 1:
+            self.local.update_force_grid_device(g.data_ptr(), g.shape[0])
+        else:
+            self.local.update_force_grid(g)
+
+    def patch_force_grid(self, first_cell, cells):
+        """Brush edit: only cells [first_cell, first_cell+len) travel."""
+        g = self._replicate_field(cells, first_cell, None)
+        first_cell = first_cell if self.world_size == 1 else self._last_first_cell
+        if self.on_gpu and self.world_size > 1:
+            self.local.patch_force_grid_device(first_cell, g.data_ptr(), g.shape[0])
+        else:
+            self.local.patch_force_grid(first_cell, g)
+
+    # -- parameters and stepping -----------------------------------------
+    def update_sim_params(self, sim_params):
+        """Replicated by value on every rank (src/compute.rs:206-219)."""
+        self.local.update_sim_params(sim_params)
+
+    def enable_step_diagnostics(self, enable=True):
+        self._diag_enabled = bool(enable)
+        self.local.enable_step_diagnostics(enable)
+
+    def compute(self):
+        """One update of the local range (src/compute.rs:221-227); with step
+        diagnostics enabled, also starts their all-reduce."""
+        self.local.compute()
+        if self._diag_enabled:
+            self._start_diag_allreduce()
+
+    def step(self, dt=None):
+        self.local.step(dt)
+        if self._diag_enabled:
+            self._start_diag_allreduce()
+
+    _RING = 8
+
+    @property
+    def _diag_buf(self):
+        if self._diag_ring is None:
+            self._diag_ring = [self._torch.zeros(48, dtype=self._torch.uint8, device=self._comm_device)
+                               for _ in range(self._RING)]
+        return self._diag_ring[self._diag_slot]
+
+    def _fill_diag_buf(self):
+        torch = self._torch
+        self._diag_slot = (self._diag_slot + 1) % self._RING
+        if self.on_gpu:
+            self.local.diagnostics_device(self._diag_buf.data_ptr())
+        else:
+            d = self.local.diagnostics()
+            host = np.zeros(48, dtype=np.uint8)
+            host[:16].view(np.float64)[:] = (float(d["count"]), d["kinetic_energy"])
+            host[16:28].view(np.float32)[:] = d["pos_max"]
+            host[28:40].view(np.float32)[:] = -np.asarray(d["pos_min"], dtype=np.float32)
+            self._diag_buf.copy_(torch.from_numpy(host))
+
+    def _start_diag_allreduce(self):
+        torch, dist = self._torch, self._dist
+        self._fill_diag_buf()
+        if self.world_size > 1:
+            sums = self._diag_buf[:16].view(torch.float64)     # count, kinetic energy
+            maxs = self._diag_buf[16:40].view(torch.float32)   # max xyz, -min xyz
+            self._pending.append(dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._pending.append(dist.all_reduce(maxs, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
+            while len(self._pending) > self._RING:   # two works per step: at most RING/2 steps in flight
+                self._pending.pop(0).wait()
+
+    def wait(self):
+        """Complete outstanding diagnostics all-reduces and the local stream."""
+        while self._pending:
+            self._pending.pop(0).wait()
+        self.local.synchronize()
+
+    def diagnostics(self):
+        """Global diagnostics of the latest state (identical on every rank)."""
+        if not self._diag_enabled:
+            self._start_diag_allreduce()
+        self.wait()
+        if self.on_gpu:
+            self._torch.cuda.current_stream().synchronize()
+        host = self._diag_buf.cpu().numpy()
+        count, ke = host[:16].view(np.float64)
+        return {"count": int(count), "kinetic_energy": float(ke),
+                "pos_max": host[16:28].view(np.float32).copy(),
+                "pos_min": -host[28:40].view(np.float32)}
+
+    # -- data access -------------------------------------------------------
+    @property
+    def num_particles(self):
+        """Global particle count (src/compute.rs:19)."""
+        return self.n_total
+
+    @property
+    def num_local_particles(self):
+        return self.last - self.first
+
+    def upload_particles(self, particles):
+        """Replace the whole set (src/compute.rs:182-196); every rank passes
+        the full array and keeps its range."""
+        particles = np.ascontiguousarray(particles).reshape(-1)
+        self.n_total = particles.shape[0]
+        self.first, self.last = shard_range(self.n_total, self.rank, self.world_size)
+        self.local.upload_particles(particles[self.first:self.last])
+
+    def read_local(self):
+        """This rank's records, global indices [self.first, self.last)."""
+        return self.local.read_particles()
+
+    def gather_particles(self):
+        """The full set in caller order on every rank (small sets / tests)."""
+        mine = self.read_local()
+        if self.world_size == 1:
+            return mine
+        parts = [None] * self.world_size
+        self._dist.all_gather_object(parts, mine, group=self.group)
+        return np.concatenate(parts)
+
+    def close(self):
+        self.wait()
+        self.local.close()

@@ -1,0 +1,68 @@
+"""Test-only stand-in for particles_amd.Compute backed by the CPU oracle.
+
+Lets the host-side sharding logic (index ranges, field broadcast, diagnostics
+all-reduce) run under gloo on a machine without a GPU.  Lives under tests/
+on purpose: the product package never falls back to the CPU."""
+import numpy as np
+
+import particles_amd as pa
+from oracle import oracle as O
+
+
+class OracleCompute:
+    def __init__(self, particles, force_grid, device=0):
+        self.p = np.ascontiguousarray(particles).view(O.PARTICLE_DTYPE).reshape(-1).copy()
+        self.g = np.ascontiguousarray(force_grid, dtype=np.float32).copy()
+        self.sp = pa.SimParams()          # src/compute.rs:33: starts as SimParams::new()
+        self.stepped = False
+
+    @classmethod
+    def new(cls, particles, force_grid, device=0):
+        return cls(particles, force_grid, device)
+
+    @property
+    def num_particles(self):
+        return self.p.shape[0]
+
+    def upload_particles(self, particles):
+        self.p = np.ascontiguousarray(particles).view(O.PARTICLE_DTYPE).reshape(-1).copy()
+
+    def generate_particles(self, n, seed, first_global_index=0, pos_extent=2.0, vel_extent=10.0):
+        self.p = O.synth_particles(n, seed, first_global_index, pos_extent, vel_extent)
+
+    def update_force_grid(self, force_grid):
+        self.g = np.ascontiguousarray(force_grid, dtype=np.float32).copy()
+
+    def patch_force_grid(self, first_cell, cells):
+        cells = np.ascontiguousarray(cells, dtype=np.float32)
+        if first_cell + cells.shape[0] > self.g.shape[0]:
+            raise pa.PclError(-4, "range outside [0, n)")
+        self.g[first_cell:first_cell + cells.shape[0]] = cells
+
+    def update_sim_params(self, sp):
+        self.sp = sp.copy()
+
+    def compute(self):
+        if self.p.shape[0]:
+            self.p = O.step(self.sp, self.p, self.g, mode=O.MODE_SKIP_INERT)
+
+    def step(self, dt=None):
+        if dt is not None:
+            self.sp.delta_t = dt
+        self.compute()
+
+    def enable_step_diagnostics(self, enable=True):
+        pass
+
+    def diagnostics(self):
+        return O.diagnostics(self.sp, self.p)
+
+    def read_particles(self, first=0, count=None):
+        count = self.p.shape[0] - first if count is None else count
+        return self.p[first:first + count].view(pa.PARTICLE_DTYPE).copy()
+
+    def synchronize(self):
+        pass
+
+    def close(self):
+        pass
