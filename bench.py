@@ -123,43 +123,23 @@ def main():
     n_local = args.particles_per_gpu
     sp = make_params(pa, dims)
 
-    # Field: built on rank 0, replicated with one broadcast over RCCL.
+    # Field: built on rank 0, replicated by ShardedCompute with one broadcast over RCCL;
+    # every rank fills its own index range with the seeded scene on the device.
     field_host = swirl_field(*dims, RADIUS, args.seed) if rank == 0 else None
-    stream = torch.cuda.current_stream()
-    c = pa.Compute.new(pa.empty_particles(0), np.zeros((1, 4), dtype=np.float32), device=local_rank)
-    c.set_stream(stream.cuda_stream)
+    sc = pa.ShardedCompute.new(None, field_host, n_total=n_local * world, seed=args.seed,
+                               pos_extent=args.pos_extent, vel_extent=10.0, device=local_rank)
+    assert sc.num_local_particles == n_local
+    c = sc.local
     c.set_tuning(args.grid_blocks, args.variant)
-    if world > 1:
-        field_dev = torch.empty((n_cells, 4), dtype=torch.float32, device="cuda")
-        if rank == 0:
-            field_dev.copy_(torch.from_numpy(field_host))
-        dist.broadcast(field_dev, src=0)
-        c.update_force_grid_device(field_dev.data_ptr(), n_cells)
-    else:
-        c.update_force_grid(field_host)
-    c.update_sim_params(sp)
-    c.generate_particles(n_local, args.seed, first_global_index=rank * n_local,
-                         pos_extent=args.pos_extent, vel_extent=10.0)
+    sc.update_sim_params(sp)
     diag_on = args.diagnostics == "on"
-    c.enable_step_diagnostics(diag_on)
-    diag_dev = torch.zeros(48, dtype=torch.uint8, device="cuda") if diag_on else None
-    pending = []
+    sc.enable_step_diagnostics(diag_on)
 
     def one_step():
-        c.compute()
-        if diag_on:
-            c.diagnostics_device(diag_dev.data_ptr())
-            if world > 1:
-                sums = diag_dev[:16].view(torch.float64)     # count, kinetic energy
-                maxs = diag_dev[16:40].view(torch.float32)   # max xyz, -min xyz
-                pending.append(dist.all_reduce(sums, op=dist.ReduceOp.SUM, async_op=True))
-                pending.append(dist.all_reduce(maxs, op=dist.ReduceOp.MAX, async_op=True))
-                while len(pending) > 8:
-                    pending.pop(0).wait()
+        sc.compute()          # one update of the local range (+ the diagnostics all-reduce when enabled)
 
     def fence():
-        while pending:
-            pending.pop(0).wait()
+        sc.wait()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -181,7 +161,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
-    diag = c.diagnostics() if rank == 0 else None
+    diag = sc.diagnostics()      # collective: global count / kinetic energy / bounds
     geometry = c.launch_geometry()
     kernel = c.last_step_kernel
 
@@ -223,13 +203,13 @@ def main():
                 "bytes_per_particle_step": BYTES_PER_PARTICLE_STEP,
                 "kernel_ms": kernel_ms,
             },
-            "final_kinetic_energy_rank0": diag["kinetic_energy"],
+            "final_diagnostics": {"count": diag["count"], "kinetic_energy": diag["kinetic_energy"]},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sp, field_host, args.seed, args.pos_extent)
         print(json.dumps(out), flush=True)
 
-    c.close()
+    sc.close()
     if world > 1:
         dist.destroy_process_group()
 
