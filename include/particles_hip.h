@@ -221,6 +221,22 @@ int pcl_synchronize(pcl_compute* h);
 int pcl_timer_start(pcl_compute* h);
 int pcl_timer_stop(pcl_compute* h, float* elapsed_ms);
 
+/* Memory order of the particles (no counterpart in the reference, which
+ * processes particles in buffer order).  While the pair term is inert the
+ * library may keep the particle arrays sorted by the field tile each particle
+ * sits in, refreshed every `interval` steps by one counting-sort pass, so that
+ * the per-particle field fetch stays cache-resident for fields larger than an
+ * XCD's L2.  Per-particle results are unchanged bit for bit and every read
+ * returns caller order.  interval: -1 automatic (default: on for fields above
+ * 2 MiB and at least 2^22 particles), 0 never, k > 0 every k steps. */
+int pcl_set_reorder_interval(pcl_compute* h, int interval);
+
+/* Sort by field tile now (also the first step does when reordering is on). */
+int pcl_reorder_now(pcl_compute* h);
+
+/* Number of sort passes run so far. */
+uint64_t pcl_reorder_count(const pcl_compute* h);
+
 /* Geometry of the streaming kernel's launch (for reports). */
 int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks,
                         uint32_t* block_threads, uint32_t* particles_per_lane);

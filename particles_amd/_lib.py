@@ -72,6 +72,9 @@ SIGNATURES = {
     "pcl_timer_start": (_i, [_vp]),
     "pcl_timer_stop": (_i, [_vp, C.POINTER(_f)]),
     "pcl_launch_geometry": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "pcl_set_reorder_interval": (_i, [_vp, _i]),
+    "pcl_reorder_now": (_i, [_vp]),
+    "pcl_reorder_count": (_u64, [_vp]),
     "pcl_set_tuning": (_i, [_vp, _u32, _u32]),
 }
 

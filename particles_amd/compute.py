@@ -200,5 +200,16 @@ class Compute:
         _lib.check(self._lib.pcl_launch_geometry(self._h, C.byref(g), C.byref(b), C.byref(p)))
         return {"grid_blocks": g.value, "block_threads": b.value, "particles_per_lane": p.value}
 
+    def set_reorder_interval(self, interval):
+        """-1 automatic, 0 never, k > 0: refresh the field-tile order every k steps."""
+        _lib.check(self._lib.pcl_set_reorder_interval(self._h, int(interval)))
+
+    def reorder_now(self):
+        _lib.check(self._lib.pcl_reorder_now(self._h))
+
+    @property
+    def reorder_count(self):
+        return int(self._lib.pcl_reorder_count(self._h))
+
     def set_tuning(self, grid_blocks=0, variant=0):
         _lib.check(self._lib.pcl_set_tuning(self._h, int(grid_blocks), int(variant)))

@@ -5,9 +5,13 @@
 //   state[2][6]  ping-pong fp32 arrays x,y,z,vx,vy,vz   (2 * 24 B per particle)
 //   ty           one byte per particle, never rewritten  (1 B per particle)
 //   field        float4 per cell
+//   ty[2], orig[2], slot_of   only once the particles are kept in field-tile
+//                order (reorder_kernels.hpp): second type array, caller index of
+//                every slot (ping-pong) and its inverse for caller-order reads
 // The step reads state[cur] and writes state[cur ^ 1], then flips `cur`
 // (reference ping-pong: src/compute.rs:147-180,221-227).
 #include "step_kernels.hpp"
+#include "reorder_kernels.hpp"
 
 #include "particles_hip.h"
 
@@ -59,6 +63,9 @@ int fail(int code, const std::string& msg)
 
 constexpr size_t kStagingRecords = size_t(1) << 22;  // AoS staging chunk: 4 Mi records = 192 MiB
 constexpr uint32_t kLdsFieldMaxBytes = 64u * 1024u;  // fields up to this size are staged in LDS
+constexpr int kAutoReorderInterval = 16;               // steps between refreshes of the tile order
+constexpr size_t kAutoReorderMinFieldBytes = size_t(2) << 20;   // fields up to 2 MiB stay L2-resident unsorted
+constexpr size_t kAutoReorderMinParticles = size_t(1) << 22;
 constexpr size_t kArrayStagger = 4096;                // see reserve_particles
 constexpr uint32_t kFoldBlocks = 64;                 // first-level blocks of the diagnostics fold
 
@@ -75,9 +82,22 @@ struct pcl_compute {
     size_t capacity = 0;
     char* slab = nullptr;              // one allocation holding every particle array
     float* state[2][6] = {{nullptr}};
-    uint8_t* ty = nullptr;
+    uint8_t* ty_buf[2] = {nullptr, nullptr};   // [1] is allocated with the reorder buffers
+    int ty_cur = 0;
     int cur = 0;
     uint64_t steps = 0;
+
+    // field-tile order (reorder_kernels.hpp)
+    int reorder_interval = -1;         // -1 automatic, 0 never, k > 0 every k steps
+    bool sorted = false;               // slots are in tile order; orig[orig_cur] holds caller indices
+    uint32_t* orig[2] = {nullptr, nullptr};
+    int orig_cur = 0;
+    uint32_t* slot_of = nullptr;       // inverse of orig, built on demand
+    bool slot_of_valid = false;
+    uint32_t* d_hist = nullptr;        // kMaxReorderBins counters + kMaxReorderBins cursors
+    size_t reorder_capacity = 0;
+    uint64_t steps_since_sort = 0;
+    uint64_t reorders = 0;
 
     pcl::f32x4* field = nullptr;
     size_t n_cells = 0;
@@ -115,9 +135,23 @@ void free_particles(pcl_compute* h)
     h->slab = nullptr;
     for (int b = 0; b < 2; ++b)
         for (int a = 0; a < 6; ++a) h->state[b][a] = nullptr;
-    h->ty = nullptr;
+    h->ty_buf[0] = nullptr;
+    h->ty_cur = 0;
     h->capacity = 0;
+    if (h->ty_buf[1]) (void)hipFree(h->ty_buf[1]);
+    h->ty_buf[1] = nullptr;
+    for (int b = 0; b < 2; ++b) {
+        if (h->orig[b]) (void)hipFree(h->orig[b]);
+        h->orig[b] = nullptr;
+    }
+    if (h->slot_of) (void)hipFree(h->slot_of);
+    h->slot_of = nullptr;
+    h->reorder_capacity = 0;
+    h->sorted = false;
+    h->slot_of_valid = false;
 }
+
+uint8_t* cur_ty(const pcl_compute* h) { return h->ty_buf[h->ty_cur]; }
 
 // The 13 particle arrays live in one allocation.  Array k starts at
 // k * (round_up(4n, 2 MiB) + 2 MiB + 4 KiB): the 4 KiB stagger keeps the 13
@@ -134,7 +168,8 @@ int reserve_particles(pcl_compute* h, size_t n)
     PCL_HIP_TRY(hipMalloc((void**)&h->slab, 13 * stride));
     for (int b = 0; b < 2; ++b)
         for (int a = 0; a < 6; ++a) h->state[b][a] = reinterpret_cast<float*>(h->slab + (size_t)(b * 6 + a) * stride);
-    h->ty = reinterpret_cast<uint8_t*>(h->slab + 12 * stride);
+    h->ty_buf[0] = reinterpret_cast<uint8_t*>(h->slab + 12 * stride);
+    h->ty_cur = 0;
     h->capacity = n;
     return PCL_OK;
 }
@@ -275,6 +310,151 @@ int launch_stream(pcl_compute* h, const pcl::StreamArgs& a, const pcl::StepUnifo
     return PCL_OK;
 }
 
+// ---- field-tile order (reorder_kernels.hpp) -------------------------------
+
+uint32_t floor_log2(uint32_t v)
+{
+    uint32_t l = 0;
+    while ((v >> (l + 1)) != 0u) ++l;
+    return l;
+}
+
+// Tiles of at most 256 cells (4 KiB of field), z extent first because z is the
+// fastest-varying cell coordinate; tiles grow until there are at most
+// kMaxReorderBins of them.
+pcl::TileMap make_tile_map(const pcl_sim_params& p)
+{
+    const uint32_t d[3] = {std::max(1u, p.force_grid_dimensions[0]), std::max(1u, p.force_grid_dimensions[1]),
+                           std::max(1u, p.force_grid_dimensions[2])};
+    uint32_t sh[3];
+    sh[2] = std::min(4u, floor_log2(d[2]));
+    sh[1] = std::min(std::min(4u, 8u - sh[2]), floor_log2(d[1]));
+    sh[0] = std::min(8u - sh[2] - sh[1], floor_log2(d[0]));
+    auto tiles = [&](int a) { return (uint64_t)((d[a] + (1u << sh[a]) - 1u) >> sh[a]); };
+    while (tiles(0) * tiles(1) * tiles(2) > pcl::kMaxReorderBins) {
+        int grow = 0;
+        for (int a = 1; a < 3; ++a)
+            if (tiles(a) > tiles(grow)) grow = a;
+        ++sh[grow];
+    }
+    pcl::TileMap T;
+    T.sx = sh[0]; T.sy = sh[1]; T.sz = sh[2];
+    T.nty = (uint32_t)tiles(1);
+    T.ntz = (uint32_t)tiles(2);
+    T.n_bins = (uint32_t)(tiles(0) * tiles(1) * tiles(2));
+    for (int a = 0; a < 3; ++a) T.max_ix[a] = d[a] - 1u;
+    return T;
+}
+
+// How often the tile order is refreshed: the caller's setting, or by default
+// every kAutoReorderInterval steps once the field no longer fits an XCD's L2
+// share and the set is large enough for the fetches to dominate.
+int effective_reorder_interval(const pcl_compute* h)
+{
+    if (h->n >= 0xFFFFFFFFull || h->n < 4096) return 0;   // caller indices are 32-bit
+    if (h->reorder_interval >= 0) return h->reorder_interval;
+    const size_t field_bytes = h->n_cells * sizeof(pcl::f32x4);
+    return (field_bytes > kAutoReorderMinFieldBytes && h->n >= kAutoReorderMinParticles) ? kAutoReorderInterval : 0;
+}
+
+int reserve_reorder(pcl_compute* h)
+{
+    if (h->reorder_capacity >= h->capacity && h->d_hist) return PCL_OK;
+    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (!h->d_hist) PCL_HIP_TRY(hipMalloc((void**)&h->d_hist, 2 * pcl::kMaxReorderBins * sizeof(uint32_t)));
+    if (h->ty_buf[1]) (void)hipFree(h->ty_buf[1]);
+    h->ty_buf[1] = nullptr;
+    for (int b = 0; b < 2; ++b) {
+        if (h->orig[b]) (void)hipFree(h->orig[b]);
+        h->orig[b] = nullptr;
+    }
+    h->reorder_capacity = 0;
+    PCL_HIP_TRY(hipMalloc((void**)&h->ty_buf[1], h->capacity));
+    for (int b = 0; b < 2; ++b) PCL_HIP_TRY(hipMalloc((void**)&h->orig[b], h->capacity * sizeof(uint32_t)));
+    h->reorder_capacity = h->capacity;
+    return PCL_OK;
+}
+
+// One counting-sort pass state[cur] -> state[cur ^ 1] by field tile of the
+// current positions; flips the state, type and caller-index buffers.
+int do_reorder(pcl_compute* h)
+{
+    if (h->n == 0) return PCL_OK;
+    if (int rc = reserve_reorder(h)) return rc;
+    const pcl::TileMap T = make_tile_map(h->params);
+    const pcl::StepUniforms U = uniforms_of(h);
+    uint32_t* hist = h->d_hist;
+    uint32_t* cursor = h->d_hist + pcl::kMaxReorderBins;
+    const size_t lds = (size_t)T.n_bins * sizeof(uint32_t);
+    PCL_HIP_TRY(hipMemsetAsync(hist, 0, T.n_bins * sizeof(uint32_t), h->stream));
+    const size_t tiles = stream_tiles(h->n);
+    const uint32_t count_grid = (uint32_t)std::min<size_t>(tiles, (size_t)h->num_cus * 8);
+    hipLaunchKernelGGL(pcl::reorder_count_kernel, dim3(count_grid), dim3(pcl::kStreamThreads), lds, h->stream,
+                       soa_of(h, h->cur), (unsigned long long)h->n, U, T, hist);
+    PCL_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(pcl::reorder_scan_kernel, dim3(1), dim3(1024), 0, h->stream, hist, T.n_bins, cursor);
+    PCL_HIP_TRY(hipGetLastError());
+    pcl::ReorderArgs a;
+    const int src = h->cur, dst = h->cur ^ 1;
+    for (int k = 0; k < 6; ++k) { a.src[k] = h->state[src][k]; a.dst[k] = h->state[dst][k]; }
+    a.src_ty = h->ty_buf[h->ty_cur];
+    a.dst_ty = h->ty_buf[h->ty_cur ^ 1];
+    a.src_orig = h->sorted ? h->orig[h->orig_cur] : nullptr;
+    a.dst_orig = h->orig[h->sorted ? (h->orig_cur ^ 1) : 0];
+    a.cursor = cursor;
+    a.n = h->n;
+    const size_t full_tiles = (h->n / 4 + pcl::kStreamThreads - 1) / pcl::kStreamThreads;
+    const size_t grid = full_tiles + ((h->n % 4) ? 1 : 0);
+    PCL_REQUIRE(grid >= 1 && grid <= 0x7FFFFFFFu, "too many particles to reorder");
+    hipLaunchKernelGGL(pcl::reorder_scatter_kernel, dim3((uint32_t)grid), dim3(pcl::kStreamThreads), lds, h->stream,
+                       a, U, T);
+    PCL_HIP_TRY(hipGetLastError());
+    h->orig_cur = h->sorted ? (h->orig_cur ^ 1) : 0;
+    h->cur = dst;
+    h->ty_cur ^= 1;
+    h->sorted = true;
+    h->slot_of_valid = false;
+    h->steps_since_sort = 0;
+    h->reorders += 1;
+    return PCL_OK;
+}
+
+// Back to caller order (the pair kernel sums over the other particles in
+// caller order, and uploads address slots by caller index).
+int restore_caller_order(pcl_compute* h)
+{
+    if (!h->sorted) return PCL_OK;
+    if (h->n) {
+        const int dst = h->cur ^ 1;
+        hipLaunchKernelGGL(pcl::restore_order_kernel, dim3(linear_grid(h, h->n)), dim3(pcl::kBlockThreads), 0,
+                           h->stream, soa_of(h, h->cur), (const uint8_t*)h->ty_buf[h->ty_cur],
+                           (const uint32_t*)h->orig[h->orig_cur], (unsigned long long)h->n, soa_of(h, dst),
+                           h->ty_buf[h->ty_cur ^ 1]);
+        PCL_HIP_TRY(hipGetLastError());
+        h->cur = dst;
+        h->ty_cur ^= 1;
+    }
+    h->sorted = false;
+    h->slot_of_valid = false;
+    return PCL_OK;
+}
+
+// Caller index -> slot map for reads; *out is null while slots are in caller order.
+int caller_order_map(pcl_compute* h, const uint32_t** out)
+{
+    *out = nullptr;
+    if (!h->sorted || h->n == 0) return PCL_OK;
+    if (!h->slot_of) PCL_HIP_TRY(hipMalloc((void**)&h->slot_of, h->capacity * sizeof(uint32_t)));
+    if (!h->slot_of_valid) {
+        hipLaunchKernelGGL(pcl::invert_permutation_kernel, dim3(linear_grid(h, h->n)), dim3(pcl::kBlockThreads), 0,
+                           h->stream, (const uint32_t*)h->orig[h->orig_cur], (unsigned long long)h->n, h->slot_of);
+        PCL_HIP_TRY(hipGetLastError());
+        h->slot_of_valid = true;
+    }
+    *out = h->slot_of;
+    return PCL_OK;
+}
+
 int do_step(pcl_compute* h)
 {
     if (int rc = bind(h)) return rc;
@@ -289,16 +469,19 @@ int do_step(pcl_compute* h)
     }
     PCL_REQUIRE(h->n_cells >= 1, "the force grid is empty");
     const pcl::StepUniforms U = uniforms_of(h);
-    const int src = h->cur, dst = h->cur ^ 1;
     uint32_t grid = 0;
 
     if (!use_pairs) {
+        const int interval = effective_reorder_interval(h);
+        if (interval > 0 && (!h->sorted || h->steps_since_sort >= (uint64_t)interval))
+            if (int rc = do_reorder(h)) return rc;
         grid = stream_grid(h);
         if (h->step_diag)
             if (int rc = reserve_partials(h, grid)) return rc;
+        const int src = h->cur, dst = h->cur ^ 1;
         pcl::StreamArgs a;
         for (int k = 0; k < 6; ++k) { a.src[k] = h->state[src][k]; a.dst[k] = h->state[dst][k]; }
-        a.ty = h->ty;
+        a.ty = cur_ty(h);
         a.field = h->field;
         a.n = h->n;
         a.partials = h->d_partials;
@@ -310,6 +493,7 @@ int do_step(pcl_compute* h)
         else              rc = nt ? launch_stream<false, true>(h, a, U, grid, lds) : launch_stream<false, false>(h, a, U, grid, lds);
         if (rc) return rc;
     } else {
+        if (int rc = restore_caller_order(h)) return rc;   // the pair sums run in caller order
         if (h->params_dirty) {
             PCL_HIP_TRY(hipMemcpyAsync(h->d_params, &h->params, sizeof(pcl_sim_params),
                                        hipMemcpyHostToDevice, h->stream));
@@ -322,9 +506,10 @@ int do_step(pcl_compute* h)
         grid = (uint32_t)blocks;
         if (h->step_diag)
             if (int rc = reserve_partials(h, grid)) return rc;
+        const int src = h->cur, dst = h->cur ^ 1;
         pcl::PairArgs a;
         for (int k = 0; k < 6; ++k) { a.src[k] = h->state[src][k]; a.dst[k] = h->state[dst][k]; }
-        a.ty = h->ty;
+        a.ty = cur_ty(h);
         a.field = h->field;
         a.params = reinterpret_cast<const pcl::ParamsBlock*>(h->d_params);
         a.n = h->n;
@@ -338,8 +523,9 @@ int do_step(pcl_compute* h)
         PCL_HIP_TRY(hipGetLastError());
     }
 
-    h->cur = dst;
+    h->cur ^= 1;
     h->steps += 1;
+    h->steps_since_sort += 1;
     if (h->step_diag) {
         if (int rc = launch_finalize(h, grid, h->d_diag)) return rc;
         h->diag_current = true;
@@ -356,7 +542,7 @@ int ensure_diag(pcl_compute* h)
     const uint32_t grid = h->n ? linear_grid(h, h->n) : 1u;
     if (int rc = reserve_partials(h, grid)) return rc;
     hipLaunchKernelGGL(pcl::diag_reduce_kernel, dim3(grid), dim3(pcl::kBlockThreads), 0, h->stream,
-                       soa_of(h, h->cur), h->ty, (unsigned long long)h->n, uniforms_of(h), h->d_partials);
+                       soa_of(h, h->cur), cur_ty(h), (unsigned long long)h->n, uniforms_of(h), h->d_partials);
     PCL_HIP_TRY(hipGetLastError());
     if (int rc = launch_finalize(h, grid, h->d_diag)) return rc;
     h->diag_current = true;
@@ -417,6 +603,7 @@ int pcl_destroy(pcl_compute* h)
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_partials) (void)hipFree(h->d_partials);
     if (h->d_diag) (void)hipFree(h->d_diag);
+    if (h->d_hist) (void)hipFree(h->d_hist);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -473,6 +660,8 @@ int pcl_create(const pcl_particle* particles, size_t n, const float (*force_grid
 int pcl_upload_particles(pcl_compute* h, const pcl_particle* particles, size_t n)
 {
     if (int rc = bind(h)) return rc;
+    h->sorted = false;          // a fresh set is in caller order
+    h->slot_of_valid = false;
     PCL_REQUIRE(n == 0 || particles != nullptr, "pcl_upload_particles: particles is null");
     for (size_t i = 0; i < n; ++i)
         if (particles[i].ty >= PCL_NUM_TYPES)
@@ -493,7 +682,7 @@ int pcl_upload_particles(pcl_compute* h, const pcl_particle* particles, size_t n
                                       hipMemcpyHostToDevice, h->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(pcl::unpack_aos_kernel, dim3(linear_grid(h, cnt)), dim3(pcl::kBlockThreads),
-                               0, h->stream, staging, (unsigned long long)cnt, soa_of(h, h->cur), h->ty,
+                               0, h->stream, staging, (unsigned long long)cnt, soa_of(h, h->cur), cur_ty(h),
                                (unsigned long long)first);
             e = hipGetLastError();
         }
@@ -508,6 +697,8 @@ int pcl_upload_particles_soa(pcl_compute* h, size_t n, const float* x, const flo
                              const float* vx, const float* vy, const float* vz, const uint8_t* ty)
 {
     if (int rc = bind(h)) return rc;
+    h->sorted = false;          // a fresh set is in caller order
+    h->slot_of_valid = false;
     const float* src[6] = {x, y, z, vx, vy, vz};
     if (n) {
         for (int a = 0; a < 6; ++a) PCL_REQUIRE(src[a] != nullptr, "pcl_upload_particles_soa: null array");
@@ -523,7 +714,7 @@ int pcl_upload_particles_soa(pcl_compute* h, size_t n, const float* x, const flo
     if (n == 0) return PCL_OK;
     for (int a = 0; a < 6; ++a)
         PCL_HIP_TRY(hipMemcpyAsync(h->state[h->cur][a], src[a], n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    PCL_HIP_TRY(hipMemcpyAsync(h->ty, ty, n, hipMemcpyHostToDevice, h->stream));
+    PCL_HIP_TRY(hipMemcpyAsync(cur_ty(h), ty, n, hipMemcpyHostToDevice, h->stream));
     PCL_HIP_TRY(hipStreamSynchronize(h->stream));
     return PCL_OK;
 }
@@ -532,12 +723,14 @@ int pcl_generate_particles(pcl_compute* h, size_t n, uint64_t seed, uint64_t fir
                            float pos_extent, float vel_extent)
 {
     if (int rc = bind(h)) return rc;
+    h->sorted = false;          // a fresh set is in caller order
+    h->slot_of_valid = false;
     if (int rc = reserve_particles(h, n)) return rc;
     h->n = n;
     h->diag_current = false;
     if (n == 0) return PCL_OK;
     hipLaunchKernelGGL(pcl::generate_kernel, dim3(linear_grid(h, n)), dim3(pcl::kBlockThreads), 0, h->stream,
-                       soa_of(h, h->cur), h->ty, (unsigned long long)n, (unsigned long long)seed,
+                       soa_of(h, h->cur), cur_ty(h), (unsigned long long)n, (unsigned long long)seed,
                        (unsigned long long)first_global_index, pos_extent, vel_extent);
     PCL_HIP_TRY(hipGetLastError());
     return PCL_OK;
@@ -625,6 +818,8 @@ int pcl_read_particles(pcl_compute* h, pcl_particle* out, size_t first, size_t c
     if (int rc = check_range(first, count, h->n, "pcl_read_particles")) return rc;
     if (count == 0) return PCL_OK;
     PCL_REQUIRE(out != nullptr, "pcl_read_particles: out is null");
+    const uint32_t* slot_of = nullptr;
+    if (int rc = caller_order_map(h, &slot_of)) return rc;
     const size_t chunk = std::min(count, kStagingRecords);
     pcl::ParticleAoS* staging = nullptr;
     PCL_HIP_TRY(hipMalloc((void**)&staging, chunk * sizeof(pcl::ParticleAoS)));
@@ -632,8 +827,8 @@ int pcl_read_particles(pcl_compute* h, pcl_particle* out, size_t first, size_t c
     for (size_t done = 0; done < count && rc == PCL_OK; done += chunk) {
         const size_t cnt = std::min(chunk, count - done);
         hipLaunchKernelGGL(pcl::pack_aos_kernel, dim3(linear_grid(h, cnt)), dim3(pcl::kBlockThreads), 0,
-                           h->stream, soa_of(h, h->cur), h->ty, (unsigned long long)(first + done),
-                           (unsigned long long)cnt, staging);
+                           h->stream, soa_of(h, h->cur), (const uint8_t*)cur_ty(h), slot_of,
+                           (unsigned long long)(first + done), (unsigned long long)cnt, staging);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess)
             e = hipMemcpyAsync(out + done, staging, cnt * sizeof(pcl_particle), hipMemcpyDeviceToHost, h->stream);
@@ -651,12 +846,33 @@ int pcl_read_soa(pcl_compute* h, size_t first, size_t count, float* x, float* y,
     if (int rc = check_range(first, count, h->n, "pcl_read_soa")) return rc;
     if (count == 0) return PCL_OK;
     float* dst[6] = {x, y, z, vx, vy, vz};
-    for (int a = 0; a < 6; ++a)
-        if (dst[a])
-            PCL_HIP_TRY(hipMemcpyAsync(dst[a], h->state[h->cur][a] + first, count * sizeof(float),
-                                       hipMemcpyDeviceToHost, h->stream));
-    if (ty) PCL_HIP_TRY(hipMemcpyAsync(ty, h->ty + first, count, hipMemcpyDeviceToHost, h->stream));
-    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+    const uint32_t* slot_of = nullptr;
+    if (int rc = caller_order_map(h, &slot_of)) return rc;
+    if (!slot_of) {
+        for (int a = 0; a < 6; ++a)
+            if (dst[a])
+                PCL_HIP_TRY(hipMemcpyAsync(dst[a], h->state[h->cur][a] + first, count * sizeof(float),
+                                           hipMemcpyDeviceToHost, h->stream));
+        if (ty) PCL_HIP_TRY(hipMemcpyAsync(ty, cur_ty(h) + first, count, hipMemcpyDeviceToHost, h->stream));
+        PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+        return PCL_OK;
+    }
+    // Tile order: gather the range into caller order on the device first.
+    char* tmp = nullptr;
+    PCL_HIP_TRY(hipMalloc((void**)&tmp, count * (6 * sizeof(float) + 1)));
+    pcl::StateSoA out;
+    for (int a = 0; a < 6; ++a) out.a[a] = reinterpret_cast<float*>(tmp) + (size_t)a * count;
+    uint8_t* out_ty = reinterpret_cast<uint8_t*>(tmp) + 6 * sizeof(float) * count;
+    hipLaunchKernelGGL(pcl::gather_soa_kernel, dim3(linear_grid(h, count)), dim3(pcl::kBlockThreads), 0, h->stream,
+                       soa_of(h, h->cur), (const uint8_t*)cur_ty(h), slot_of, (unsigned long long)first,
+                       (unsigned long long)count, out, out_ty);
+    hipError_t e = hipGetLastError();
+    for (int a = 0; a < 6 && e == hipSuccess; ++a)
+        if (dst[a]) e = hipMemcpyAsync(dst[a], out.a[a], count * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    if (ty && e == hipSuccess) e = hipMemcpyAsync(ty, out_ty, count, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(PCL_ERR_HIP, std::string("pcl_read_soa: ") + hipGetErrorString(e));
     return PCL_OK;
 }
 
@@ -666,8 +882,10 @@ int pcl_pack_particles_device(pcl_compute* h, void* dev_out, size_t first, size_
     if (int rc = check_range(first, count, h->n, "pcl_pack_particles_device")) return rc;
     if (count == 0) return PCL_OK;
     PCL_REQUIRE(dev_out != nullptr, "pcl_pack_particles_device: dev_out is null");
+    const uint32_t* slot_of = nullptr;
+    if (int rc = caller_order_map(h, &slot_of)) return rc;
     hipLaunchKernelGGL(pcl::pack_aos_kernel, dim3(linear_grid(h, count)), dim3(pcl::kBlockThreads), 0,
-                       h->stream, soa_of(h, h->cur), h->ty, (unsigned long long)first,
+                       h->stream, soa_of(h, h->cur), (const uint8_t*)cur_ty(h), slot_of, (unsigned long long)first,
                        (unsigned long long)count, reinterpret_cast<pcl::ParticleAoS*>(dev_out));
     PCL_HIP_TRY(hipGetLastError());
     return PCL_OK;
@@ -699,10 +917,12 @@ int pcl_debug_cell_indices(pcl_compute* h, uint32_t* out, size_t first, size_t c
     if (count == 0) return PCL_OK;
     PCL_REQUIRE(out != nullptr, "pcl_debug_cell_indices: out is null");
     PCL_REQUIRE(h->n_cells >= 1, "the force grid is empty");
+    const uint32_t* slot_of = nullptr;
+    if (int rc = caller_order_map(h, &slot_of)) return rc;
     uint32_t* d = nullptr;
     PCL_HIP_TRY(hipMalloc((void**)&d, count * sizeof(uint32_t)));
     hipLaunchKernelGGL(pcl::cell_index_kernel, dim3(linear_grid(h, count)), dim3(pcl::kBlockThreads), 0,
-                       h->stream, soa_of(h, h->cur), (unsigned long long)first, (unsigned long long)count,
+                       h->stream, soa_of(h, h->cur), slot_of, (unsigned long long)first, (unsigned long long)count,
                        uniforms_of(h), d);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, count * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
@@ -754,6 +974,23 @@ int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks, uint32_t* b
     if (particles_per_lane) *particles_per_lane = pcl::kParticlesPerLane;
     return PCL_OK;
 }
+
+int pcl_set_reorder_interval(pcl_compute* h, int interval)
+{
+    if (!h) return fail(PCL_ERR_INVALID, "null handle");
+    PCL_REQUIRE(interval >= -1, "pcl_set_reorder_interval: interval must be -1 (automatic), 0 (never) or positive");
+    h->reorder_interval = interval;
+    return PCL_OK;
+}
+
+int pcl_reorder_now(pcl_compute* h)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_REQUIRE(h->n < 0xFFFFFFFFull, "pcl_reorder_now: more than 2^32 - 2 particles");
+    return do_reorder(h);
+}
+
+uint64_t pcl_reorder_count(const pcl_compute* h) { return h ? h->reorders : 0; }
 
 int pcl_set_tuning(pcl_compute* h, uint32_t grid_blocks, uint32_t variant)
 {

@@ -1,0 +1,213 @@
+// reorder_kernels.hpp — keeps the particle arrays in field-tile order.
+//
+// The update of one particle depends only on its own state (pair term inert),
+// so the order of the particles in memory is free.  The only non-streaming
+// access of the step is one 16-byte field fetch per particle; with particles
+// in arbitrary order and a field larger than an XCD's 4 MiB L2 most of those
+// fetches leave the L2, and each costs as much fabric traffic as a particle's
+// whole stream.  Storing the particles sorted by the field tile they sit in
+// makes concurrently running workgroups touch a few adjacent tiles, so the
+// fetches hit L1/L2 again.  Particles drift a few cells per step, so the order
+// is refreshed every few steps by one counting-sort pass:
+//   count   : histogram of tile keys                      (reads x, y, z)
+//   scan    : exclusive prefix over the bins               (one block)
+//   scatter : every tile of 2048 particles reserves, per bin it touches, a
+//             contiguous segment with one atomic add, and writes its
+//             particles there (state, type and the caller's index).
+// Results per particle are unchanged bit for bit; `orig` remembers the
+// caller's index of every slot so that read-back returns caller order.
+// No counterpart in the reference (src/compute.wgsl processes particles in
+// buffer order and never reorders them).
+#pragma once
+
+#include "step_kernels.hpp"
+
+namespace pcl {
+
+constexpr uint32_t kMaxReorderBins = 8192;
+
+// Field tiles of (1<<sx) x (1<<sy) x (1<<sz) cells, enumerated x-tile slowest
+// like the cells themselves.
+struct TileMap {
+    uint32_t sx, sy, sz;     // log2 of the tile extent per axis
+    uint32_t nty, ntz;       // tiles along y and z
+    uint32_t n_bins;
+    uint32_t max_ix[3];      // dim - 1 per axis (an index equal to dim is clamped)
+};
+
+__device__ __forceinline__ uint32_t tile_key(const StepUniforms& U, const TileMap& T,
+                                             float x, float y, float z)
+{
+    uint32_t ix = 0u, iy = 0u, iz = 0u;
+    if (!U.degenerate) {
+        ix = (uint32_t)map_range_axis(U, x, U.span_b[0]);
+        iy = (uint32_t)map_range_axis(U, y, U.span_b[1]);
+        iz = (uint32_t)map_range_axis(U, z, U.span_b[2]);
+    }
+    ix = ix < T.max_ix[0] ? ix : T.max_ix[0];
+    iy = iy < T.max_ix[1] ? iy : T.max_ix[1];
+    iz = iz < T.max_ix[2] ? iz : T.max_ix[2];
+    return ((ix >> T.sx) * T.nty + (iy >> T.sy)) * T.ntz + (iz >> T.sz);
+}
+
+// Histogram of tile keys: persistent blocks, LDS counters, one global atomic
+// add per non-empty bin and block.
+__global__ __launch_bounds__(kStreamThreads) void reorder_count_kernel(
+    StateSoA s, unsigned long long n, StepUniforms U, TileMap T, uint32_t* __restrict__ hist)
+{
+    extern __shared__ uint32_t lds_hist[];
+    for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) lds_hist[b] = 0u;
+    __syncthreads();
+    const unsigned long long n_groups = n / 4ull;
+    const unsigned long long stride = (unsigned long long)gridDim.x * kStreamThreads;
+    for (unsigned long long g = (unsigned long long)blockIdx.x * kStreamThreads + threadIdx.x;
+         g < n_groups; g += stride) {
+        const f32x4 X = load4<false>(s.a[0], g);
+        const f32x4 Y = load4<false>(s.a[1], g);
+        const f32x4 Z = load4<false>(s.a[2], g);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(&lds_hist[tile_key(U, T, X[k], Y[k], Z[k])], 1u);
+    }
+    const unsigned long long tail = n_groups * 4ull + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 3 && tail < n)
+        atomicAdd(&lds_hist[tile_key(U, T, s.a[0][tail], s.a[1][tail], s.a[2][tail])], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) {
+        const uint32_t c = lds_hist[b];
+        if (c) atomicAdd(&hist[b], c);
+    }
+}
+
+// Exclusive prefix of hist[0..n_bins) into cursor[0..n_bins); one block.
+__global__ __launch_bounds__(1024) void reorder_scan_kernel(const uint32_t* __restrict__ hist,
+                                                            uint32_t n_bins, uint32_t* __restrict__ cursor)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (n_bins + 1023u) / 1024u;
+    const uint32_t begin = threadIdx.x * per;
+    uint32_t sum = 0u;
+    for (uint32_t i = 0; i < per; ++i)
+        if (begin + i < n_bins) sum += hist[begin + i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {   // Hillis-Steele inclusive scan
+        const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+    for (uint32_t i = 0; i < per; ++i)
+        if (begin + i < n_bins) {
+            cursor[begin + i] = run;
+            run += hist[begin + i];
+        }
+}
+
+struct ReorderArgs {
+    const float* __restrict__ src[6];
+    float* __restrict__ dst[6];
+    const uint8_t* __restrict__ src_ty;
+    uint8_t* __restrict__ dst_ty;
+    const uint32_t* __restrict__ src_orig;  // nullptr: slots are still in caller order
+    uint32_t* __restrict__ dst_orig;
+    uint32_t* __restrict__ cursor;          // next free slot per bin
+    unsigned long long n;
+};
+
+// One tile of 2048 consecutive source particles per block (plus one block for
+// the ragged tail when n is not a multiple of 4).
+__global__ __launch_bounds__(kStreamThreads) void reorder_scatter_kernel(ReorderArgs a, StepUniforms U,
+                                                                         TileMap T)
+{
+    extern __shared__ uint32_t lds[];
+    uint32_t* count = lds;               // particles of this tile per bin, then the bin's base slot
+    for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) count[b] = 0u;
+    __syncthreads();
+
+    const unsigned long long n_groups = a.n / 4ull;
+    const unsigned long long g = (unsigned long long)blockIdx.x * kStreamThreads + threadIdx.x;
+    const bool full = g < n_groups;
+    // Up to 3 particles past the last full group: the host appends one block
+    // that holds no full group, and its lanes 0..2 carry them.
+    const unsigned long long tail = n_groups * 4ull + threadIdx.x;
+    const bool is_tail = !full && blockIdx.x == gridDim.x - 1 && threadIdx.x < 3 && tail < a.n;
+
+    f32x4 V[6];
+    uint32_t t4 = 0u, key[4], rank[4], orig[4];
+    if (full) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) V[c] = load4<true>(a.src[c], g);
+        t4 = reinterpret_cast<const uint32_t*>(a.src_ty)[g];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            orig[k] = a.src_orig ? a.src_orig[g * 4ull + k] : (uint32_t)(g * 4ull + k);
+            key[k] = tile_key(U, T, V[0][k], V[1][k], V[2][k]);
+            rank[k] = atomicAdd(&count[key[k]], 1u);
+        }
+    } else if (is_tail) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) V[c][0] = a.src[c][tail];
+        t4 = a.src_ty[tail];
+        orig[0] = a.src_orig ? a.src_orig[tail] : (uint32_t)tail;
+        key[0] = tile_key(U, T, V[0][0], V[1][0], V[2][0]);
+        rank[0] = atomicAdd(&count[key[0]], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) {
+        const uint32_t c = count[b];
+        if (c) count[b] = atomicAdd(&a.cursor[b], c);
+    }
+    __syncthreads();
+    const int live = full ? 4 : (is_tail ? 1 : 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < live) {
+            const uint32_t d = count[key[k]] + rank[k];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) a.dst[c][d] = V[c][k];
+            a.dst_ty[d] = (uint8_t)((t4 >> (8 * k)) & 0xFFu);
+            a.dst_orig[d] = orig[k];
+        }
+    }
+}
+
+// slot_of[orig[i]] = i: where each caller index lives.
+__global__ __launch_bounds__(kBlockThreads) void invert_permutation_kernel(
+    const uint32_t* __restrict__ orig, unsigned long long n, uint32_t* __restrict__ slot_of)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x; i < n; i += stride)
+        slot_of[orig[i]] = (uint32_t)i;
+}
+
+// Back to caller order: dst[orig[i]] = src[i].
+__global__ __launch_bounds__(kBlockThreads) void restore_order_kernel(
+    StateSoA src, const uint8_t* __restrict__ src_ty, const uint32_t* __restrict__ orig,
+    unsigned long long n, StateSoA dst, uint8_t* __restrict__ dst_ty)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x; i < n; i += stride) {
+        const uint32_t d = orig[i];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) dst.a[c][d] = src.a[c][i];
+        dst_ty[d] = src_ty[i];
+    }
+}
+
+// Caller-order gather of a range: out arrays indexed by (caller index - first).
+__global__ __launch_bounds__(kBlockThreads) void gather_soa_kernel(
+    StateSoA s, const uint8_t* __restrict__ ty, const uint32_t* __restrict__ slot_of,
+    unsigned long long first, unsigned long long count, StateSoA out, uint8_t* __restrict__ out_ty)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x; i < count; i += stride) {
+        const uint32_t slot = slot_of[first + i];
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+            if (out.a[c]) out.a[c][i] = s.a[c][slot];
+        if (out_ty) out_ty[i] = ty[slot];
+    }
+}
+
+}  // namespace pcl

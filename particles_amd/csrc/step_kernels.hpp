@@ -508,14 +508,15 @@ __global__ __launch_bounds__(kBlockThreads) void unpack_aos_kernel(
 }
 
 // Writes what wgsl:180 writes: w lanes 1.0, padding 0.
+// `slot_of` (may be null) maps a caller index to the slot that holds it.
 __global__ __launch_bounds__(kBlockThreads) void pack_aos_kernel(
-    StateSoA s, const uint8_t* __restrict__ ty, unsigned long long first,
-    unsigned long long count, ParticleAoS* __restrict__ out)
+    StateSoA s, const uint8_t* __restrict__ ty, const uint32_t* __restrict__ slot_of,
+    unsigned long long first, unsigned long long count, ParticleAoS* __restrict__ out)
 {
     const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
     for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x;
          i < count; i += stride) {
-        const unsigned long long o = first + i;
+        const unsigned long long o = slot_of ? slot_of[first + i] : first + i;
         const f32x4 p = {s.a[0][o], s.a[1][o], s.a[2][o], 1.0f};
         const f32x4 v = {s.a[3][o], s.a[4][o], s.a[5][o], 1.0f};
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -527,13 +528,13 @@ __global__ __launch_bounds__(kBlockThreads) void pack_aos_kernel(
 }
 
 __global__ __launch_bounds__(kBlockThreads) void cell_index_kernel(
-    StateSoA s, unsigned long long first, unsigned long long count, StepUniforms U,
-    uint32_t* __restrict__ out)
+    StateSoA s, const uint32_t* __restrict__ slot_of, unsigned long long first,
+    unsigned long long count, StepUniforms U, uint32_t* __restrict__ out)
 {
     const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
     for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x;
          i < count; i += stride) {
-        const unsigned long long o = first + i;
+        const unsigned long long o = slot_of ? slot_of[first + i] : first + i;
         out[i] = cell_index(U, s.a[0][o], s.a[1][o], s.a[2][o]);
     }
 }

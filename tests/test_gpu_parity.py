@@ -206,3 +206,77 @@ def test_lds_field_path_large_n(oracle):
     p = oracle.synth_particles(5000, seed=77, first_global_index=n - 5000, pos_extent=20.0, vel_extent=10.0)
     want = oracle.run(sp, p, g, 2, mode=oracle.MODE_SKIP_INERT)
     assert_particles_bit_equal(got, want, "LDS-staged field")
+
+
+# ---- field-tile order: results and read-back are independent of the memory order
+
+@pytest.mark.parametrize("n,interval", [(4096, 1), (4099, 2), (100003, 3), (300001, 5)])
+def test_reorder_keeps_results_and_caller_order(oracle, n, interval):
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = (128, 64, 2)
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    g = scene_swirl_field(128, 64, 2, 10.0, seed=3)
+    p = oracle.synth_particles(n, seed=n, pos_extent=20.0, vel_extent=10.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        c.set_reorder_interval(interval)
+        c.enable_step_diagnostics(True)
+        for _ in range(7):
+            c.compute()
+        assert c.reorder_count >= 7 // interval
+        want = oracle.run(sp, p, g, 7, mode=oracle.MODE_SKIP_INERT)
+        assert_particles_bit_equal(c.read_particles(), want, f"tile order n={n}")
+        assert_particles_bit_equal(c.read_particles(1000, 2000), want[1000:3000], "sub-range in caller order")
+        soa = c.read_soa(17, 500)
+        assert np.array_equal(soa["vy"], want["vel"][17:517, 1]) and np.array_equal(soa["ty"], want["ty"][17:517])
+        assert np.array_equal(c.debug_cell_indices(), oracle.cell_indices(sp, want, g.shape[0]))
+        d, wd = c.diagnostics(), oracle.diagnostics(sp, want)
+        assert d["count"] == n and abs(d["kinetic_energy"] - wd["kinetic_energy"]) <= 1e-12 * wd["kinetic_energy"]
+        assert np.array_equal(d["pos_max"], wd["pos_max"]) and np.array_equal(d["pos_min"], wd["pos_min"])
+        # a fresh upload is back in caller order
+        c.upload_particles(p)
+        c.compute()
+        assert_particles_bit_equal(c.read_particles(), oracle.run(sp, p, g, 1, mode=oracle.MODE_SKIP_INERT), "after upload")
+
+
+def test_pair_kernel_after_reorder_runs_in_caller_order(oracle):
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    g = sp.new_force_grid_centered().get_force_vectors()
+    p = oracle.synth_particles(5000, seed=12, pos_extent=4.0, vel_extent=10.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        c.set_reorder_interval(1)
+        c.compute()
+        c.compute()
+        assert c.reorder_count == 2
+        mid = oracle.run(sp, p, g, 2, mode=oracle.MODE_SKIP_INERT)
+        sp2 = pair_params(0.0)
+        c.update_sim_params(sp2)
+        c.compute()
+        assert c.last_step_kernel == pa.KERNEL_PAIRS
+        assert_particles_bit_equal(c.read_particles(), oracle.run(sp2, mid, g, 1), "pairs after tile order")
+
+
+def test_full_size_slices_match_oracle(oracle):
+    """2^26 particles generated on the device, 1024^2 field, automatic tile
+    order: particles are independent, so slices of the big run are checked
+    against the oracle stepping the same global indices."""
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = (1024, 1024, 1)
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    g = scene_swirl_field(1024, 1024, 1, 10.0, seed=5)
+    n = 1 << 26
+    with pa.Compute.new(pa.empty_particles(0), g) as c:
+        c.update_sim_params(sp)
+        c.generate_particles(n, seed=2025, pos_extent=20.0, vel_extent=10.0)
+        for _ in range(20):
+            c.compute()
+        assert c.reorder_count >= 2          # automatic: field > 2 MiB, n >= 2^22
+        for first in (0, 12345678, n - 4000):
+            p = oracle.synth_particles(4000, seed=2025, first_global_index=first, pos_extent=20.0, vel_extent=10.0)
+            want = oracle.run(sp, p, g, 20, mode=oracle.MODE_SKIP_INERT)
+            assert_particles_bit_equal(c.read_particles(first, 4000), want, f"slice at {first}")
+        assert c.diagnostics()["count"] == n
