@@ -97,6 +97,7 @@ struct pcl_compute {
     uint32_t* d_hist = nullptr;        // kMaxReorderBins counters + kMaxReorderBins cursors
     size_t reorder_capacity = 0;
     uint64_t steps_since_sort = 0;
+    bool hist_valid = false;           // d_hist counts the tile keys of state[cur] (left by a counting step)
     uint64_t reorders = 0;
 
     pcl::f32x4* field = nullptr;
@@ -295,16 +296,20 @@ int launch_finalize(pcl_compute* h, uint32_t n_partials, pcl::DiagOut* dev_out)
 }
 
 template <bool DIAG, bool NT>
-int launch_stream(pcl_compute* h, const pcl::StreamArgs& a, const pcl::StepUniforms& U, uint32_t grid,
-                  bool lds)
+int launch_stream(pcl_compute* h, const pcl::StreamArgs& a, const pcl::StepUniforms& U, const pcl::TileMap& T,
+                  uint32_t grid, bool lds, bool count)
 {
     if (lds) {
         const size_t bytes = (size_t)a.lds_cells * sizeof(pcl::f32x4);
-        hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, true>), dim3(grid),
-                           dim3(pcl::kStreamThreads), bytes, h->stream, a, U);
+        hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, true, false>), dim3(grid),
+                           dim3(pcl::kStreamThreads), bytes, h->stream, a, U, T);
+    } else if (count) {
+        const size_t bytes = (size_t)T.n_bins * sizeof(uint32_t);
+        hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, false, true>), dim3(grid),
+                           dim3(pcl::kStreamThreads), bytes, h->stream, a, U, T);
     } else {
-        hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, false>), dim3(grid),
-                           dim3(pcl::kStreamThreads), 0, h->stream, a, U);
+        hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, false, false>), dim3(grid),
+                           dim3(pcl::kStreamThreads), 0, h->stream, a, U, T);
     }
     PCL_HIP_TRY(hipGetLastError());
     return PCL_OK;
@@ -352,6 +357,7 @@ pcl::TileMap make_tile_map(const pcl_sim_params& p)
 int effective_reorder_interval(const pcl_compute* h)
 {
     if (h->n >= 0xFFFFFFFFull || h->n < 4096) return 0;   // caller indices are 32-bit
+    if (use_lds_field(h)) return 0;                       // the whole field sits in LDS: order is irrelevant
     if (h->reorder_interval >= 0) return h->reorder_interval;
     const size_t field_bytes = h->n_cells * sizeof(pcl::f32x4);
     return (field_bytes > kAutoReorderMinFieldBytes && h->n >= kAutoReorderMinParticles) ? kAutoReorderInterval : 0;
@@ -375,47 +381,72 @@ int reserve_reorder(pcl_compute* h)
     return PCL_OK;
 }
 
+// Histogram of the tile keys of the current positions into d_hist (separate
+// pass; a preceding counting step leaves the same histogram for free).
+int reorder_count(pcl_compute* h, const pcl::StepUniforms& U, const pcl::TileMap& T)
+{
+    uint32_t* hist = h->d_hist;
+    PCL_HIP_TRY(hipMemsetAsync(hist, 0, T.n_bins * sizeof(uint32_t), h->stream));
+    const uint32_t count_grid = (uint32_t)std::min<size_t>(stream_tiles(h->n), (size_t)h->num_cus * 8);
+    hipLaunchKernelGGL(pcl::reorder_count_kernel, dim3(count_grid), dim3(pcl::kStreamThreads),
+                       (size_t)T.n_bins * sizeof(uint32_t), h->stream, soa_of(h, h->cur), (unsigned long long)h->n,
+                       U, T, hist);
+    PCL_HIP_TRY(hipGetLastError());
+    return PCL_OK;
+}
+
+// Exclusive scan of d_hist into the cursors and the argument block of a
+// scatter from state[cur] into state[cur ^ 1].
+int reorder_prepare(pcl_compute* h, const pcl::TileMap& T, pcl::ReorderArgs* a, uint32_t* grid)
+{
+    uint32_t* hist = h->d_hist;
+    uint32_t* cursor = h->d_hist + pcl::kMaxReorderBins;
+    hipLaunchKernelGGL(pcl::reorder_scan_kernel, dim3(1), dim3(1024), 0, h->stream, hist, T.n_bins, cursor);
+    PCL_HIP_TRY(hipGetLastError());
+    const int src = h->cur, dst = h->cur ^ 1;
+    for (int k = 0; k < 6; ++k) { a->src[k] = h->state[src][k]; a->dst[k] = h->state[dst][k]; }
+    a->src_ty = h->ty_buf[h->ty_cur];
+    a->dst_ty = h->ty_buf[h->ty_cur ^ 1];
+    a->src_orig = h->sorted ? h->orig[h->orig_cur] : nullptr;
+    a->dst_orig = h->orig[h->sorted ? (h->orig_cur ^ 1) : 0];
+    a->cursor = cursor;
+    a->n = h->n;
+    const size_t full_tiles = (h->n / 4 + pcl::kStreamThreads - 1) / pcl::kStreamThreads;
+    const size_t g = full_tiles + ((h->n % 4) ? 1 : 0);   // one extra block carries the ragged tail
+    PCL_REQUIRE(g >= 1 && g <= 0x7FFFFFFFu, "too many particles to reorder");
+    *grid = (uint32_t)g;
+    return PCL_OK;
+}
+
+// Bookkeeping after a scatter pass wrote state[cur ^ 1].
+void reorder_commit(pcl_compute* h)
+{
+    h->orig_cur = h->sorted ? (h->orig_cur ^ 1) : 0;
+    h->cur ^= 1;
+    h->ty_cur ^= 1;
+    h->sorted = true;
+    h->slot_of_valid = false;
+    h->hist_valid = false;
+    h->reorders += 1;
+}
+
 // One counting-sort pass state[cur] -> state[cur ^ 1] by field tile of the
-// current positions; flips the state, type and caller-index buffers.
+// current positions (no time step).
 int do_reorder(pcl_compute* h)
 {
     if (h->n == 0) return PCL_OK;
     if (int rc = reserve_reorder(h)) return rc;
     const pcl::TileMap T = make_tile_map(h->params);
     const pcl::StepUniforms U = uniforms_of(h);
-    uint32_t* hist = h->d_hist;
-    uint32_t* cursor = h->d_hist + pcl::kMaxReorderBins;
-    const size_t lds = (size_t)T.n_bins * sizeof(uint32_t);
-    PCL_HIP_TRY(hipMemsetAsync(hist, 0, T.n_bins * sizeof(uint32_t), h->stream));
-    const size_t tiles = stream_tiles(h->n);
-    const uint32_t count_grid = (uint32_t)std::min<size_t>(tiles, (size_t)h->num_cus * 8);
-    hipLaunchKernelGGL(pcl::reorder_count_kernel, dim3(count_grid), dim3(pcl::kStreamThreads), lds, h->stream,
-                       soa_of(h, h->cur), (unsigned long long)h->n, U, T, hist);
-    PCL_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(pcl::reorder_scan_kernel, dim3(1), dim3(1024), 0, h->stream, hist, T.n_bins, cursor);
-    PCL_HIP_TRY(hipGetLastError());
+    if (int rc = reorder_count(h, U, T)) return rc;
     pcl::ReorderArgs a;
-    const int src = h->cur, dst = h->cur ^ 1;
-    for (int k = 0; k < 6; ++k) { a.src[k] = h->state[src][k]; a.dst[k] = h->state[dst][k]; }
-    a.src_ty = h->ty_buf[h->ty_cur];
-    a.dst_ty = h->ty_buf[h->ty_cur ^ 1];
-    a.src_orig = h->sorted ? h->orig[h->orig_cur] : nullptr;
-    a.dst_orig = h->orig[h->sorted ? (h->orig_cur ^ 1) : 0];
-    a.cursor = cursor;
-    a.n = h->n;
-    const size_t full_tiles = (h->n / 4 + pcl::kStreamThreads - 1) / pcl::kStreamThreads;
-    const size_t grid = full_tiles + ((h->n % 4) ? 1 : 0);
-    PCL_REQUIRE(grid >= 1 && grid <= 0x7FFFFFFFu, "too many particles to reorder");
-    hipLaunchKernelGGL(pcl::reorder_scatter_kernel, dim3((uint32_t)grid), dim3(pcl::kStreamThreads), lds, h->stream,
-                       a, U, T);
+    uint32_t grid = 0;
+    if (int rc = reorder_prepare(h, T, &a, &grid)) return rc;
+    hipLaunchKernelGGL(pcl::reorder_scatter_kernel, dim3(grid), dim3(pcl::kStreamThreads),
+                       (size_t)T.n_bins * sizeof(uint32_t), h->stream, a, U, T);
     PCL_HIP_TRY(hipGetLastError());
-    h->orig_cur = h->sorted ? (h->orig_cur ^ 1) : 0;
-    h->cur = dst;
-    h->ty_cur ^= 1;
-    h->sorted = true;
-    h->slot_of_valid = false;
+    reorder_commit(h);
     h->steps_since_sort = 0;
-    h->reorders += 1;
     return PCL_OK;
 }
 
@@ -436,6 +467,7 @@ int restore_caller_order(pcl_compute* h)
     }
     h->sorted = false;
     h->slot_of_valid = false;
+    h->hist_valid = false;
     return PCL_OK;
 }
 
@@ -471,29 +503,67 @@ int do_step(pcl_compute* h)
     const pcl::StepUniforms U = uniforms_of(h);
     uint32_t grid = 0;
 
+    bool flipped = false;   // the launch already flipped the buffers
     if (!use_pairs) {
         const int interval = effective_reorder_interval(h);
-        if (interval > 0 && (!h->sorted || h->steps_since_sort >= (uint64_t)interval))
-            if (int rc = do_reorder(h)) return rc;
-        grid = stream_grid(h);
-        if (h->step_diag)
-            if (int rc = reserve_partials(h, grid)) return rc;
-        const int src = h->cur, dst = h->cur ^ 1;
-        pcl::StreamArgs a;
-        for (int k = 0; k < 6; ++k) { a.src[k] = h->state[src][k]; a.dst[k] = h->state[dst][k]; }
-        a.ty = cur_ty(h);
-        a.field = h->field;
-        a.n = h->n;
-        a.partials = h->d_partials;
-        const bool lds = use_lds_field(h);
-        a.lds_cells = lds ? (uint32_t)h->n_cells : 0u;
-        const bool nt = (h->variant & 1u) == 0;
-        int rc;
-        if (h->step_diag) rc = nt ? launch_stream<true, true>(h, a, U, grid, lds) : launch_stream<true, false>(h, a, U, grid, lds);
-        else              rc = nt ? launch_stream<false, true>(h, a, U, grid, lds) : launch_stream<false, false>(h, a, U, grid, lds);
-        if (rc) return rc;
+        const bool sort_now = interval > 0 && (!h->sorted || h->steps_since_sort >= (uint64_t)interval);
+        const pcl::TileMap T = make_tile_map(h->params);
+        if (sort_now) {
+            // Update and scatter into tile order in one pass.
+            if (int rc = reserve_reorder(h)) return rc;
+            if (!h->hist_valid)
+                if (int rc = reorder_count(h, U, T)) return rc;
+            pcl::StepScatterArgs sa;
+            if (int rc = reorder_prepare(h, T, &sa.r, &grid)) return rc;
+            if (h->step_diag)
+                if (int rc = reserve_partials(h, grid)) return rc;
+            sa.field = h->field;
+            sa.partials = h->d_partials;
+            const size_t lds_bytes = (size_t)T.n_bins * sizeof(uint32_t);
+            if (h->step_diag)
+                hipLaunchKernelGGL((pcl::step_scatter_kernel<true>), dim3(grid), dim3(pcl::kStreamThreads), lds_bytes,
+                                   h->stream, sa, U, T);
+            else
+                hipLaunchKernelGGL((pcl::step_scatter_kernel<false>), dim3(grid), dim3(pcl::kStreamThreads), lds_bytes,
+                                   h->stream, sa, U, T);
+            PCL_HIP_TRY(hipGetLastError());
+            reorder_commit(h);
+            h->steps_since_sort = 0;   // incremented below: the new order is one step old
+            flipped = true;
+        } else {
+            // The step before a sort also histograms its output positions.
+            const bool count = interval > 1 && h->sorted && h->steps_since_sort + 1 >= (uint64_t)interval &&
+                               (h->variant & 8u) == 0;
+            grid = stream_grid(h);
+            if (count) {
+                if (int rc = reserve_reorder(h)) return rc;
+                // One tile per block here too: blocks dispatched together then work on
+                // neighbouring tiles, which is what keeps the field fetches cache-resident
+                // (a persistent grid striding over the array measured 15 % slower).
+                PCL_HIP_TRY(hipMemsetAsync(h->d_hist, 0, T.n_bins * sizeof(uint32_t), h->stream));
+            }
+            if (h->step_diag)
+                if (int rc = reserve_partials(h, grid)) return rc;
+            const int src = h->cur, dst = h->cur ^ 1;
+            pcl::StreamArgs a;
+            for (int k = 0; k < 6; ++k) { a.src[k] = h->state[src][k]; a.dst[k] = h->state[dst][k]; }
+            a.ty = cur_ty(h);
+            a.field = h->field;
+            a.n = h->n;
+            a.partials = h->d_partials;
+            a.hist = h->d_hist;
+            const bool lds = use_lds_field(h);
+            a.lds_cells = lds ? (uint32_t)h->n_cells : 0u;
+            const bool nt = (h->variant & 1u) == 0;
+            int rc;
+            if (h->step_diag) rc = nt ? launch_stream<true, true>(h, a, U, T, grid, lds, count) : launch_stream<true, false>(h, a, U, T, grid, lds, count);
+            else              rc = nt ? launch_stream<false, true>(h, a, U, T, grid, lds, count) : launch_stream<false, false>(h, a, U, T, grid, lds, count);
+            if (rc) return rc;
+            h->hist_valid = count;
+        }
     } else {
         if (int rc = restore_caller_order(h)) return rc;   // the pair sums run in caller order
+        h->hist_valid = false;
         if (h->params_dirty) {
             PCL_HIP_TRY(hipMemcpyAsync(h->d_params, &h->params, sizeof(pcl_sim_params),
                                        hipMemcpyHostToDevice, h->stream));
@@ -523,7 +593,7 @@ int do_step(pcl_compute* h)
         PCL_HIP_TRY(hipGetLastError());
     }
 
-    h->cur ^= 1;
+    if (!flipped) h->cur ^= 1;
     h->steps += 1;
     h->steps_since_sort += 1;
     if (h->step_diag) {
@@ -662,6 +732,7 @@ int pcl_upload_particles(pcl_compute* h, const pcl_particle* particles, size_t n
     if (int rc = bind(h)) return rc;
     h->sorted = false;          // a fresh set is in caller order
     h->slot_of_valid = false;
+    h->hist_valid = false;
     PCL_REQUIRE(n == 0 || particles != nullptr, "pcl_upload_particles: particles is null");
     for (size_t i = 0; i < n; ++i)
         if (particles[i].ty >= PCL_NUM_TYPES)
@@ -699,6 +770,7 @@ int pcl_upload_particles_soa(pcl_compute* h, size_t n, const float* x, const flo
     if (int rc = bind(h)) return rc;
     h->sorted = false;          // a fresh set is in caller order
     h->slot_of_valid = false;
+    h->hist_valid = false;
     const float* src[6] = {x, y, z, vx, vy, vz};
     if (n) {
         for (int a = 0; a < 6; ++a) PCL_REQUIRE(src[a] != nullptr, "pcl_upload_particles_soa: null array");
@@ -725,6 +797,7 @@ int pcl_generate_particles(pcl_compute* h, size_t n, uint64_t seed, uint64_t fir
     if (int rc = bind(h)) return rc;
     h->sorted = false;          // a fresh set is in caller order
     h->slot_of_valid = false;
+    h->hist_valid = false;
     if (int rc = reserve_particles(h, n)) return rc;
     h->n = n;
     h->diag_current = false;
@@ -776,6 +849,10 @@ int pcl_update_sim_params(pcl_compute* h, const pcl_sim_params* params)
 {
     if (!h) return fail(PCL_ERR_INVALID, "null handle");
     PCL_REQUIRE(params != nullptr, "pcl_update_sim_params: params is null");
+    // the field dimensions and the radius define the tile keys of a pending histogram
+    if (std::memcmp(h->params.force_grid_dimensions, params->force_grid_dimensions, sizeof params->force_grid_dimensions) != 0 ||
+        std::memcmp(&h->params.bounding_volume_radius, &params->bounding_volume_radius, sizeof(float)) != 0)
+        h->hist_valid = false;
     h->params = *params;
     h->params_dirty = true;
     h->diag_current = false;  // the masses weight the kinetic energy
@@ -980,6 +1057,7 @@ int pcl_set_reorder_interval(pcl_compute* h, int interval)
     if (!h) return fail(PCL_ERR_INVALID, "null handle");
     PCL_REQUIRE(interval >= -1, "pcl_set_reorder_interval: interval must be -1 (automatic), 0 (never) or positive");
     h->reorder_interval = interval;
+    h->hist_valid = false;
     return PCL_OK;
 }
 

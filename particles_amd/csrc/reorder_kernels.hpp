@@ -26,30 +26,6 @@ namespace pcl {
 
 constexpr uint32_t kMaxReorderBins = 8192;
 
-// Field tiles of (1<<sx) x (1<<sy) x (1<<sz) cells, enumerated x-tile slowest
-// like the cells themselves.
-struct TileMap {
-    uint32_t sx, sy, sz;     // log2 of the tile extent per axis
-    uint32_t nty, ntz;       // tiles along y and z
-    uint32_t n_bins;
-    uint32_t max_ix[3];      // dim - 1 per axis (an index equal to dim is clamped)
-};
-
-__device__ __forceinline__ uint32_t tile_key(const StepUniforms& U, const TileMap& T,
-                                             float x, float y, float z)
-{
-    uint32_t ix = 0u, iy = 0u, iz = 0u;
-    if (!U.degenerate) {
-        ix = (uint32_t)map_range_axis(U, x, U.span_b[0]);
-        iy = (uint32_t)map_range_axis(U, y, U.span_b[1]);
-        iz = (uint32_t)map_range_axis(U, z, U.span_b[2]);
-    }
-    ix = ix < T.max_ix[0] ? ix : T.max_ix[0];
-    iy = iy < T.max_ix[1] ? iy : T.max_ix[1];
-    iz = iz < T.max_ix[2] ? iz : T.max_ix[2];
-    return ((ix >> T.sx) * T.nty + (iy >> T.sy)) * T.ntz + (iz >> T.sz);
-}
-
 // Histogram of tile keys: persistent blocks, LDS counters, one global atomic
 // add per non-empty bin and block.
 __global__ __launch_bounds__(kStreamThreads) void reorder_count_kernel(
@@ -66,7 +42,7 @@ __global__ __launch_bounds__(kStreamThreads) void reorder_count_kernel(
         const f32x4 Y = load4<false>(s.a[1], g);
         const f32x4 Z = load4<false>(s.a[2], g);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) atomicAdd(&lds_hist[tile_key(U, T, X[k], Y[k], Z[k])], 1u);
+        for (int k = 0; k < 4; ++k) lds_rank_add(lds_hist, tile_key(U, T, X[k], Y[k], Z[k]), true);
     }
     const unsigned long long tail = n_groups * 4ull + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < 3 && tail < n)
@@ -140,18 +116,18 @@ __global__ __launch_bounds__(kStreamThreads) void reorder_scatter_kernel(Reorder
         for (int c = 0; c < 6; ++c) V[c] = load4<true>(a.src[c], g);
         t4 = reinterpret_cast<const uint32_t*>(a.src_ty)[g];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            orig[k] = a.src_orig ? a.src_orig[g * 4ull + k] : (uint32_t)(g * 4ull + k);
-            key[k] = tile_key(U, T, V[0][k], V[1][k], V[2][k]);
-            rank[k] = atomicAdd(&count[key[k]], 1u);
-        }
+        for (int k = 0; k < 4; ++k) orig[k] = a.src_orig ? a.src_orig[g * 4ull + k] : (uint32_t)(g * 4ull + k);
     } else if (is_tail) {
 #pragma unroll
         for (int c = 0; c < 6; ++c) V[c][0] = a.src[c][tail];
         t4 = a.src_ty[tail];
         orig[0] = a.src_orig ? a.src_orig[tail] : (uint32_t)tail;
-        key[0] = tile_key(U, T, V[0][0], V[1][0], V[2][0]);
-        rank[0] = atomicAdd(&count[key[0]], 1u);
+    }
+    const int live_in = full ? 4 : (is_tail ? 1 : 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {   // every lane takes part: lds_rank_add is a wave-wide operation
+        key[k] = k < live_in ? tile_key(U, T, V[0][k], V[1][k], V[2][k]) : 0u;
+        rank[k] = lds_rank_add(count, key[k], k < live_in);
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) {
@@ -170,6 +146,91 @@ __global__ __launch_bounds__(kStreamThreads) void reorder_scatter_kernel(Reorder
             a.dst_orig[d] = orig[k];
         }
     }
+}
+
+// The update and the scatter in one pass: every particle is advanced one step
+// (exactly as step_stream_kernel does) and its new state is written to the slot
+// its bin assigns, the bin being the field tile of the position it had BEFORE
+// the step (one step stale, which is what the histogram in `cursor` counted).
+// Saves the extra read and write of a separate reorder pass.
+struct StepScatterArgs {
+    ReorderArgs r;
+    const f32x4* __restrict__ field;
+    DiagPartial* partials;
+};
+
+template <bool DIAG>
+__global__ __launch_bounds__(kStreamThreads) void step_scatter_kernel(StepScatterArgs sa, StepUniforms U, TileMap T)
+{
+    const ReorderArgs& a = sa.r;
+    extern __shared__ uint32_t lds[];
+    uint32_t* count = lds;
+    for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) count[b] = 0u;
+    __syncthreads();
+
+    const unsigned long long n_groups = a.n / 4ull;
+    const unsigned long long g = (unsigned long long)blockIdx.x * kStreamThreads + threadIdx.x;
+    const bool full = g < n_groups;
+    const unsigned long long tail = n_groups * 4ull + threadIdx.x;
+    const bool is_tail = !full && blockIdx.x == gridDim.x - 1 && threadIdx.x < 3 && tail < a.n;
+    const int live = full ? 4 : (is_tail ? 1 : 0);
+
+    DiagAcc acc;
+    if (DIAG) acc.init();
+
+    f32x4 V[6];
+    uint32_t t4 = 0u, key[4], rank[4], orig[4];
+    if (full) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) V[c] = load4<true>(a.src[c], g);
+        t4 = reinterpret_cast<const uint32_t*>(a.src_ty)[g];
+        if (a.src_orig) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 o = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.src_orig) + g);
+            orig[0] = o.x; orig[1] = o.y; orig[2] = o.z; orig[3] = o.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) orig[k] = (uint32_t)(g * 4ull + k);
+        }
+    } else if (is_tail) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) V[c][0] = a.src[c][tail];
+        t4 = a.src_ty[tail];
+        orig[0] = a.src_orig ? a.src_orig[tail] : (uint32_t)tail;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {   // every lane takes part: lds_rank_add is a wave-wide operation
+        key[k] = k < live ? tile_key(U, T, V[0][k], V[1][k], V[2][k]) : 0u;
+        rank[k] = lds_rank_add(count, key[k], k < live);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < live) {
+            const f32x4 f = sa.field[cell_index(U, V[0][k], V[1][k], V[2][k])];
+            const float m = mass_of(U, (t4 >> (8 * k)) & 0xFFu);
+            float x = V[0][k], y = V[1][k], z = V[2][k], vx = V[3][k], vy = V[4][k], vz = V[5][k];
+            integrate(U, f.x, f.y, f.z, m, 0.0f, 0.0f, 0.0f, x, y, z, vx, vy, vz);
+            V[0][k] = x; V[1][k] = y; V[2][k] = z; V[3][k] = vx; V[4][k] = vy; V[5][k] = vz;
+            if (DIAG) acc.add(m, x, y, z, vx, vy, vz);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) {
+        const uint32_t c = count[b];
+        if (c) count[b] = atomicAdd(&a.cursor[b], c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < live) {
+            const uint32_t d = count[key[k]] + rank[k];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) a.dst[c][d] = V[c][k];
+            a.dst_ty[d] = (uint8_t)((t4 >> (8 * k)) & 0xFFu);
+            a.dst_orig[d] = orig[k];
+        }
+    }
+    if (DIAG) block_reduce_store<kStreamThreads>(acc, sa.partials + blockIdx.x);
 }
 
 // slot_of[orig[i]] = i: where each caller index lives.

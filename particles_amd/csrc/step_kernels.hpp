@@ -256,6 +256,60 @@ __global__ __launch_bounds__(kBlockThreads) void diag_fold_kernel(
 
 // ------------------------------------------------------ streaming kernel K1
 
+// Field tiles of (1<<sx) x (1<<sy) x (1<<sz) cells, enumerated x-tile slowest
+// like the cells themselves; the sort key of the field-tile particle order
+// (reorder_kernels.hpp).
+struct TileMap {
+    uint32_t sx, sy, sz;     // log2 of the tile extent per axis
+    uint32_t nty, ntz;       // tiles along y and z
+    uint32_t n_bins;
+    uint32_t max_ix[3];      // dim - 1 per axis (an index equal to dim is clamped)
+};
+
+__device__ __forceinline__ uint32_t tile_key(const StepUniforms& U, const TileMap& T,
+                                             float x, float y, float z)
+{
+    uint32_t ix = 0u, iy = 0u, iz = 0u;
+    if (!U.degenerate) {
+        ix = (uint32_t)map_range_axis(U, x, U.span_b[0]);
+        iy = (uint32_t)map_range_axis(U, y, U.span_b[1]);
+        iz = (uint32_t)map_range_axis(U, z, U.span_b[2]);
+    }
+    ix = ix < T.max_ix[0] ? ix : T.max_ix[0];
+    iy = iy < T.max_ix[1] ? iy : T.max_ix[1];
+    iz = iz < T.max_ix[2] ? iz : T.max_ix[2];
+    return ((ix >> T.sx) * T.nty + (iy >> T.sy)) * T.ntz + (iz >> T.sz);
+}
+
+// counters[key] += 1 for every active lane, returning each lane's rank within
+// its counter.  Particles kept in tile order make most lanes of a wave share
+// one key, and 64 same-address LDS atomics serialise; so lanes with equal keys
+// are combined into one add by their first lane (up to 4 distinct keys per
+// call, then plain per-lane atomics for what is left).
+__device__ __forceinline__ uint32_t lds_rank_add(uint32_t* counters, uint32_t key, bool active)
+{
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    uint32_t rank = 0u;
+    unsigned long long todo = __ballot(active);
+    for (int iter = 0; todo != 0ull; ++iter) {
+        if (iter == 4) {
+            if ((todo >> lane) & 1ull) rank = atomicAdd(&counters[key], 1u);
+            break;
+        }
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t lk = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+        const bool mine = ((todo >> lane) & 1ull) && key == lk;
+        const unsigned long long same = __ballot(mine);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
+        uint32_t base = 0u;
+        if (lane == leader) base = atomicAdd(&counters[lk], (uint32_t)__popcll(same));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        if (mine) rank = base + below;
+        todo &= ~same;
+    }
+    return rank;
+}
+
 struct StreamArgs {
     const float* __restrict__ src[6];
     float* __restrict__ dst[6];
@@ -264,6 +318,7 @@ struct StreamArgs {
     unsigned long long n;
     DiagPartial* partials;  // one per block when DIAG
     uint32_t lds_cells;     // cells staged in LDS when FIELD_LDS
+    uint32_t* hist;         // global tile histogram when COUNT
 };
 
 template <bool NT>
@@ -292,14 +347,23 @@ __device__ __forceinline__ void store4(float* base, unsigned long long group, f3
 constexpr int kStreamThreads = 512;  // 8 waves
 constexpr int kStreamTile = kStreamThreads * kParticlesPerLane;
 
-template <bool DIAG, bool NT, bool FIELD_LDS>
-__global__ __launch_bounds__(kStreamThreads) void step_stream_kernel(StreamArgs a, StepUniforms U)
+// COUNT: also histogram the field tile of every OUTPUT position into a.hist
+// (LDS counters per persistent block, one global atomic per non-empty bin), so
+// that the next step can be a step_scatter_kernel without a counting pass.
+// FIELD_LDS and COUNT are exclusive (both use the dynamic LDS).
+template <bool DIAG, bool NT, bool FIELD_LDS, bool COUNT = false>
+__global__ __launch_bounds__(kStreamThreads) void step_stream_kernel(StreamArgs a, StepUniforms U, TileMap T)
 {
     // Small fields (<= 64 KiB) are staged in LDS once per persistent block;
     // larger ones are fetched through L2 / Infinity Cache.
     extern __shared__ __attribute__((aligned(16))) f32x4 lds_field[];
+    uint32_t* lds_hist = reinterpret_cast<uint32_t*>(lds_field);
     if (FIELD_LDS) {
         for (uint32_t c = threadIdx.x; c < a.lds_cells; c += kStreamThreads) lds_field[c] = a.field[c];
+        __syncthreads();
+    }
+    if (COUNT) {
+        for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) lds_hist[b] = 0u;
         __syncthreads();
     }
     auto fetch = [&](uint32_t c) -> f32x4 { return FIELD_LDS ? lds_field[c] : a.field[c]; };
@@ -332,6 +396,7 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_kernel(StreamArgs 
             integrate(U, F[k].x, F[k].y, F[k].z, m, 0.0f, 0.0f, 0.0f, x, y, z, vx, vy, vz);
             X[k] = x; Y[k] = y; Z[k] = z; VX[k] = vx; VY[k] = vy; VZ[k] = vz;
             if (DIAG) acc.add(m, x, y, z, vx, vy, vz);
+            if (COUNT) lds_rank_add(lds_hist, tile_key(U, T, x, y, z), true);
         }
 
         store4<NT>(a.dst[0], g, X);
@@ -353,8 +418,16 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_kernel(StreamArgs 
         a.dst[0][tail] = x; a.dst[1][tail] = y; a.dst[2][tail] = z;
         a.dst[3][tail] = vx; a.dst[4][tail] = vy; a.dst[5][tail] = vz;
         if (DIAG) acc.add(m, x, y, z, vx, vy, vz);
+        if (COUNT) atomicAdd(&lds_hist[tile_key(U, T, x, y, z)], 1u);
     }
 
+    if (COUNT) {
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) {
+            const uint32_t c = lds_hist[b];
+            if (c) atomicAdd(&a.hist[b], c);
+        }
+    }
     if (DIAG) block_reduce_store<kStreamThreads>(acc, a.partials + blockIdx.x);
 }
 
