@@ -7,9 +7,11 @@ HIPFLAGS  ?= -O3 --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math -fPIC -
 
 LIB       := particles_amd/libparticles_hip.so
 SRC       := particles_amd/csrc/particles_hip.hip
-HDRS      := particles_amd/csrc/step_kernels.hpp include/particles_hip.h
+HDRS      := particles_amd/csrc/step_kernels.hpp particles_amd/csrc/reorder_kernels.hpp include/particles_hip.h
 
-all: $(LIB) oracle
+CPPTEST   := tests/cpp/compute_wrapper_test
+
+all: $(LIB) oracle $(CPPTEST)
 
 $(LIB): $(SRC) $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRC)
@@ -17,12 +19,16 @@ $(LIB): $(SRC) $(HDRS)
 oracle:
 	$(MAKE) -C oracle
 
+# Host-only program over the C++ mirror of the reference's Compute; plain g++.
+$(CPPTEST): tests/cpp/compute_wrapper_test.cpp include/particles_compute.hpp include/particles_hip.h $(LIB)
+	g++ -O2 -std=c++17 -Wall -Wextra -Iinclude -o $@ $< -Lparticles_amd -lparticles_hip -Wl,-rpath,'$$ORIGIN/../../particles_amd' -Wl,-rpath-link,/opt/rocm/lib
+
 asm: $(SRC) $(HDRS)
 	mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build/particles_hip.s $(SRC) -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt
 
 clean:
-	rm -f $(LIB)
+	rm -f $(LIB) $(CPPTEST)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle asm clean

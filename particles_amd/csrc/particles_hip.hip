@@ -63,7 +63,7 @@ int fail(int code, const std::string& msg)
 
 constexpr size_t kStagingRecords = size_t(1) << 22;  // AoS staging chunk: 4 Mi records = 192 MiB
 constexpr uint32_t kLdsFieldMaxBytes = 64u * 1024u;  // fields up to this size are staged in LDS
-constexpr int kAutoReorderInterval = 16;               // steps between refreshes of the tile order
+constexpr int kAutoReorderInterval = 8;                // steps between refreshes of the tile order
 constexpr size_t kAutoReorderMinFieldBytes = size_t(2) << 20;   // fields up to 2 MiB stay L2-resident unsorted
 constexpr size_t kAutoReorderMinParticles = size_t(1) << 22;
 constexpr size_t kArrayStagger = 4096;                // see reserve_particles

@@ -280,3 +280,17 @@ def test_full_size_slices_match_oracle(oracle):
             want = oracle.run(sp, p, g, 20, mode=oracle.MODE_SKIP_INERT)
             assert_particles_bit_equal(c.read_particles(first, 4000), want, f"slice at {first}")
         assert c.diagnostics()["count"] == n
+
+
+def test_cpp_host_mirror_matches_oracle(oracle, tmp_path):
+    """include/particles_compute.hpp driven like the reference's App
+    (per frame: update_force_grid, update_sim_params, compute)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "compute_wrapper_test")
+    out = tmp_path / "cpp_out.bin"
+    subprocess.run([exe, str(out), "6"], check=True, timeout=120)
+    got = np.fromfile(out, dtype=pa.PARTICLE_DTYPE)
+    sp, p, g = default_scene()
+    sp.delta_t = DT
+    assert_particles_bit_equal(got, oracle.run(sp, p, g, 6), "C++ host mirror")
