@@ -60,6 +60,18 @@ def make_params(pa, dims):
     return sp
 
 
+def measured_traffic(n_local, dims, pos_extent):
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC
+    passes (profiles/traffic.json), or None when this workload was not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            table = json.load(f)
+        rec = table.get(f"{n_local}|{dims[0]}x{dims[1]}x{dims[2]}|{float(pos_extent)}")
+        return rec["hbm_bytes"] if rec else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(sp, field, seed, pos_extent, budget_s=12.0):
     """Time the CPU oracle (scalar C restatement of the shader, same pair-skip
     rule, index-range split over host threads) on a bounded sample of the same
@@ -74,7 +86,7 @@ def cpu_baseline(sp, field, seed, pos_extent, budget_s=12.0):
         p = O.step(sp, p, field, mode=O.MODE_SKIP_INERT, threads=threads)
         steps += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or steps >= 64:
+        if el >= budget_s or steps >= 256:
             break
     return {
         "value": n * steps / el,
@@ -205,7 +217,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(n_local, dims, args.pos_extent),
                 "bytes_per_particle_step": BYTES_PER_PARTICLE_STEP,
                 "kernel_ms": kernel_ms,
                 "note": "kernel_ms = HIP-event time of the timed region / steps on the kernel's stream; it includes "

@@ -66,6 +66,7 @@ constexpr uint32_t kLdsFieldMaxBytes = 64u * 1024u;  // fields up to this size a
 constexpr int kAutoReorderInterval = 8;                // steps between refreshes of the tile order
 constexpr size_t kAutoReorderMinFieldBytes = size_t(2) << 20;   // fields up to 2 MiB stay L2-resident unsorted
 constexpr size_t kAutoReorderMinParticles = size_t(1) << 22;
+constexpr size_t kPairSmallSet = size_t(1) << 18;     // up to here the pair kernel runs one wave per block
 constexpr size_t kArrayStagger = 4096;                // see reserve_particles
 constexpr uint32_t kFoldBlocks = 64;                 // first-level blocks of the diagnostics fold
 
@@ -229,6 +230,23 @@ pcl::StepUniforms uniforms_of(const pcl_compute* h)
     U.degenerate = (U.neg_slh == U.slh) ? 1u : 0u;              // wgsl:69
     for (int k = 0; k < 5; ++k) U.mass[k] = p.particle_type_masses[k].mass;
     return U;
+}
+
+// Smallest non-negative float s (by bit pattern, +inf included) for which
+// pred(sqrtf(s)) holds, pred being monotone (false ... false true ... true);
+// NaN when it never holds.  sqrtf is correctly rounded on the host and in the
+// kernel, so the threshold transfers exactly.
+template <typename Pred>
+float smallest_square_with(Pred pred)
+{
+    auto from_bits = [](uint32_t b) { float f; std::memcpy(&f, &b, sizeof f); return f; };
+    uint32_t lo = 0u, hi = 0x7F800000u;   // +0 .. +inf
+    if (!pred(std::sqrt(from_bits(hi)))) return std::nanf("");
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (pred(std::sqrt(from_bits(mid)))) hi = mid; else lo = mid + 1;
+    }
+    return from_bits(lo);
 }
 
 // The pair loop adds exactly +0 to the acceleration when every polynomial
@@ -571,7 +589,10 @@ int do_step(pcl_compute* h)
             PCL_HIP_TRY(hipStreamSynchronize(h->stream));
             h->params_dirty = false;
         }
-        const size_t blocks = (h->n + pcl::kBlockThreads - 1) / pcl::kBlockThreads;
+        // One wave per block while the set is small (more CUs busy), four otherwise.
+        const bool small = h->n <= kPairSmallSet;
+        const size_t pb = small ? 64 : pcl::kBlockThreads;
+        const size_t blocks = (h->n + pb - 1) / pb;
         PCL_REQUIRE(blocks <= 0x7FFFFFFFu, "too many particles for the pair kernel");
         grid = (uint32_t)blocks;
         if (h->step_diag)
@@ -584,12 +605,22 @@ int do_step(pcl_compute* h)
         a.params = reinterpret_cast<const pcl::ParamsBlock*>(h->d_params);
         a.n = h->n;
         a.partials = h->d_partials;
-        if (h->step_diag)
-            hipLaunchKernelGGL((pcl::step_pairs_kernel<true>), dim3(grid), dim3(pcl::kBlockThreads), 0,
-                               h->stream, a, U);
-        else
-            hipLaunchKernelGGL((pcl::step_pairs_kernel<false>), dim3(grid), dim3(pcl::kBlockThreads), 0,
-                               h->stream, a, U);
+        a.s_near = smallest_square_with([](float len) { return !(len < 0.001f); });
+        const float cut = h->params.cut_off_distance;
+        a.s_far = smallest_square_with([cut](float len) { return len > cut; });
+        if (small) {
+            if (h->step_diag)
+                hipLaunchKernelGGL((pcl::step_pairs_kernel<true, 64>), dim3(grid), dim3(64), 0, h->stream, a, U);
+            else
+                hipLaunchKernelGGL((pcl::step_pairs_kernel<false, 64>), dim3(grid), dim3(64), 0, h->stream, a, U);
+        } else {
+            if (h->step_diag)
+                hipLaunchKernelGGL((pcl::step_pairs_kernel<true, pcl::kBlockThreads>), dim3(grid),
+                                   dim3(pcl::kBlockThreads), 0, h->stream, a, U);
+            else
+                hipLaunchKernelGGL((pcl::step_pairs_kernel<false, pcl::kBlockThreads>), dim3(grid),
+                                   dim3(pcl::kBlockThreads), 0, h->stream, a, U);
+        }
         PCL_HIP_TRY(hipGetLastError());
     }
 

@@ -466,24 +466,32 @@ struct PairArgs {
     const ParamsBlock* __restrict__ params;
     unsigned long long n;
     DiagPartial* partials;
+    // Thresholds on the SQUARED distance s, found on the host by bisection over
+    // the float bit patterns, such that with the correctly rounded square root
+    //   sqrtf(s) < 0.001f          <=>  s <  s_near     (wgsl:126)
+    //   sqrtf(s) > cut_off_distance <=>  s >= s_far      (wgsl:129)
+    // so rejected pairs never pay for the square root.
+    float s_near;
+    float s_far;
 };
 
-// All-pairs attraction (wgsl:111-144) tiled through LDS: a block owns 256
-// particles, every tile of 256 source particles is staged once per block as
-// (x, y, z, type) and swept by all lanes in index order, so each particle's
-// sum is accumulated in the shader's order j = 0..N-1.
-template <bool DIAG>
-__global__ __launch_bounds__(kBlockThreads) void step_pairs_kernel(PairArgs a, StepUniforms U)
+// All-pairs attraction (wgsl:111-144) tiled through LDS: a block owns PB
+// particles (one per lane), every tile of PB source particles is staged once
+// per block as (x, y, z, type) and swept by all lanes in index order, so each
+// particle's sum is accumulated in the shader's order j = 0..N-1 (bit-exact;
+// the price is that the parallelism is N lanes, no split of the j range).
+// PB = 64 (one wave per block) spreads small sets over more CUs.
+template <bool DIAG, int PB>
+__global__ __launch_bounds__(PB) void step_pairs_kernel(PairArgs a, StepUniforms U)
 {
-    __shared__ f32x4 tile[kBlockThreads];
+    __shared__ f32x4 tile[PB];
     __shared__ float polys[25 * 8];
 
-    for (int k = threadIdx.x; k < 25 * 8; k += kBlockThreads)
+    for (int k = threadIdx.x; k < 25 * 8; k += PB)
         polys[k] = a.params->polys[k / 8][k % 8];
-    const float cut_off = a.params->cut_off_distance;
     const float exponent = a.params->distance_exponent;
 
-    const unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x;
+    const unsigned long long i = (unsigned long long)blockIdx.x * PB + threadIdx.x;
     const bool live = i < a.n;
     float x = 0.f, y = 0.f, z = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
     uint32_t my_ty = 0u;
@@ -492,9 +500,10 @@ __global__ __launch_bounds__(kBlockThreads) void step_pairs_kernel(PairArgs a, S
         vx = a.src[3][i]; vy = a.src[4][i]; vz = a.src[5][i];
         my_ty = a.ty[i];
     }
+    const float* my_polys = &polys[my_ty * 5u * 8u];
     float ax = 0.0f, ay = 0.0f, az = 0.0f;
 
-    for (unsigned long long base = 0; base < a.n; base += kBlockThreads) {
+    for (unsigned long long base = 0; base < a.n; base += PB) {
         __syncthreads();
         const unsigned long long j = base + threadIdx.x;
         f32x4 t = {0.f, 0.f, 0.f, 0.f};
@@ -505,20 +514,22 @@ __global__ __launch_bounds__(kBlockThreads) void step_pairs_kernel(PairArgs a, S
         tile[threadIdx.x] = t;
         __syncthreads();
         const unsigned long long rem = a.n - base;
-        const int cnt = rem < (unsigned long long)kBlockThreads ? (int)rem : kBlockThreads;
+        const int cnt = rem < (unsigned long long)PB ? (int)rem : PB;
+        // lane-local index of this particle inside the tile, or -1: wgsl:120-122
+        const int self = (live && i >= base && i < base + (unsigned long long)cnt) ? (int)(i - base) : -1;
         if (live) {
+#pragma unroll 4
             for (int jj = 0; jj < cnt; ++jj) {
-                if (base + jj == i) continue;                       // wgsl:120-122
                 const f32x4 o = tile[jj];
                 const float dx = o.x - x, dy = o.y - y, dz = o.z - z;
-                const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
-                if (len < 0.001f) continue;                         // wgsl:126-128
-                if (len > cut_off) continue;                        // wgsl:129-131
+                const float s = (dx * dx + dy * dy) + dz * dz;
+                if (jj == self || s < a.s_near || s >= a.s_far) continue;   // wgsl:120-131
+                const float len = sqrtf(s);
                 // pow(x, 0) is exactly 1 for every finite positive x
                 const float df = exponent == 0.0f ? 1.0f : powf(len, exponent);
                 const uint32_t oty = __float_as_uint(o.w);
                 const float m2 = mass_of(U, oty);
-                const float pv = eval_poly7(len, &polys[(oty + my_ty * 5u) * 8u]);
+                const float pv = eval_poly7(len, &my_polys[oty * 8u]);
                 ax = ax + ((__fdiv_rn(dx, len) * pv) * m2) * df;    // wgsl:139
                 ay = ay + ((__fdiv_rn(dy, len) * pv) * m2) * df;
                 az = az + ((__fdiv_rn(dz, len) * pv) * m2) * df;
@@ -536,7 +547,7 @@ __global__ __launch_bounds__(kBlockThreads) void step_pairs_kernel(PairArgs a, S
         a.dst[3][i] = vx; a.dst[4][i] = vy; a.dst[5][i] = vz;
         if (DIAG) acc.add(m, x, y, z, vx, vy, vz);
     }
-    if (DIAG) block_reduce_store(acc, a.partials + blockIdx.x);
+    if (DIAG) block_reduce_store<PB>(acc, a.partials + blockIdx.x);
 }
 
 // ------------------------------------------------- standalone diagnostics K3

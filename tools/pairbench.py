@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Timing of the general (all-pairs) kernel at the reference's operating sizes (GPU only)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import particles_amd as pa
+
+
+def main():
+    sp = pa.SimParams()
+    sp.delta_t = np.float32(1 / 60)
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    sp.polys[:] = np.random.default_rng(1).uniform(-1, 1, size=(25, 8)).astype(np.float32)
+    g = sp.new_force_grid_centered().get_force_vectors()
+    for exponent in (0.0, -1.0):
+        sp.distance_exponent = exponent
+        for extent in (2.0, 20.0):
+            for n in (1000, 4096, 16384, 50000, 131072):
+                with pa.Compute.new(pa.empty_particles(0), g) as c:
+                    c.update_sim_params(sp)
+                    c.generate_particles(n, 7, 0, extent, 10.0)
+                    for _ in range(2):
+                        c.compute()
+                    c.synchronize()
+                    steps = 10 if n <= 50000 else 3
+                    c.timer_start()
+                    for _ in range(steps):
+                        c.compute()
+                    ms = c.timer_stop() / steps
+                    assert c.last_step_kernel == pa.KERNEL_PAIRS
+                    print(f"exponent {exponent:4.1f} extent {extent:4.1f} n {n:7d}: {ms:9.4f} ms/step  "
+                          f"{n * n / ms / 1e6:9.2f} G pair visits/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
