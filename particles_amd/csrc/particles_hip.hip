@@ -63,7 +63,7 @@ int fail(int code, const std::string& msg)
 
 constexpr size_t kStagingRecords = size_t(1) << 22;  // AoS staging chunk: 4 Mi records = 192 MiB
 constexpr uint32_t kLdsFieldMaxBytes = 64u * 1024u;  // fields up to this size are staged in LDS
-constexpr int kAutoReorderInterval = 8;                // steps between refreshes of the tile order
+constexpr int kAutoReorderInterval = 12;               // steps between refreshes of the tile order
 constexpr size_t kAutoReorderMinFieldBytes = size_t(2) << 20;   // fields up to 2 MiB stay L2-resident unsorted
 constexpr size_t kAutoReorderMinParticles = size_t(1) << 22;
 constexpr size_t kPairSmallSet = size_t(1) << 18;     // up to here the pair kernel runs one wave per block
@@ -99,6 +99,7 @@ struct pcl_compute {
     size_t reorder_capacity = 0;
     uint64_t steps_since_sort = 0;
     bool hist_valid = false;           // d_hist counts the tile keys of state[cur] (left by a counting step)
+    pcl::TileMap hist_tiles;           // the key function that histogram was taken with
     uint64_t reorders = 0;
 
     pcl::f32x4* field = nullptr;
@@ -345,7 +346,7 @@ uint32_t floor_log2(uint32_t v)
 // Tiles of at most 256 cells (4 KiB of field), z extent first because z is the
 // fastest-varying cell coordinate; tiles grow until there are at most
 // kMaxReorderBins of them.
-pcl::TileMap make_tile_map(const pcl_sim_params& p)
+pcl::TileMap make_tile_map(const pcl_sim_params& p, int interval)
 {
     const uint32_t d[3] = {std::max(1u, p.force_grid_dimensions[0]), std::max(1u, p.force_grid_dimensions[1]),
                            std::max(1u, p.force_grid_dimensions[2])};
@@ -366,6 +367,8 @@ pcl::TileMap make_tile_map(const pcl_sim_params& p)
     T.ntz = (uint32_t)tiles(2);
     T.n_bins = (uint32_t)(tiles(0) * tiles(1) * tiles(2));
     for (int a = 0; a < 3; ++a) T.max_ix[a] = d[a] - 1u;
+    // aim the order at the middle of the refresh interval
+    T.lookahead = interval > 1 ? p.delta_t * (0.5f * (float)interval) : 0.0f;
     return T;
 }
 
@@ -454,7 +457,7 @@ int do_reorder(pcl_compute* h)
 {
     if (h->n == 0) return PCL_OK;
     if (int rc = reserve_reorder(h)) return rc;
-    const pcl::TileMap T = make_tile_map(h->params);
+    const pcl::TileMap T = make_tile_map(h->params, effective_reorder_interval(h));
     const pcl::StepUniforms U = uniforms_of(h);
     if (int rc = reorder_count(h, U, T)) return rc;
     pcl::ReorderArgs a;
@@ -525,7 +528,8 @@ int do_step(pcl_compute* h)
     if (!use_pairs) {
         const int interval = effective_reorder_interval(h);
         const bool sort_now = interval > 0 && (!h->sorted || h->steps_since_sort >= (uint64_t)interval);
-        const pcl::TileMap T = make_tile_map(h->params);
+        // A pending histogram fixes the key function (delta_t, hence the lookahead, may change per frame).
+        const pcl::TileMap T = (sort_now && h->hist_valid) ? h->hist_tiles : make_tile_map(h->params, interval);
         if (sort_now) {
             // Update and scatter into tile order in one pass.
             if (int rc = reserve_reorder(h)) return rc;
@@ -578,6 +582,7 @@ int do_step(pcl_compute* h)
             else              rc = nt ? launch_stream<false, true>(h, a, U, T, grid, lds, count) : launch_stream<false, false>(h, a, U, T, grid, lds, count);
             if (rc) return rc;
             h->hist_valid = count;
+            if (count) h->hist_tiles = T;
         }
     } else {
         if (int rc = restore_caller_order(h)) return rc;   // the pair sums run in caller order

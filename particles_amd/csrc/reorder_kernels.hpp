@@ -9,7 +9,7 @@
 // makes concurrently running workgroups touch a few adjacent tiles, so the
 // fetches hit L1/L2 again.  Particles drift a few cells per step, so the order
 // is refreshed every few steps by one counting-sort pass:
-//   count   : histogram of tile keys                      (reads x, y, z)
+//   count   : histogram of tile keys                      (reads the state)
 //   scan    : exclusive prefix over the bins               (one block)
 //   scatter : every tile of 2048 particles reserves, per bin it touches, a
 //             contiguous segment with one atomic add, and writes its
@@ -38,15 +38,16 @@ __global__ __launch_bounds__(kStreamThreads) void reorder_count_kernel(
     const unsigned long long stride = (unsigned long long)gridDim.x * kStreamThreads;
     for (unsigned long long g = (unsigned long long)blockIdx.x * kStreamThreads + threadIdx.x;
          g < n_groups; g += stride) {
-        const f32x4 X = load4<false>(s.a[0], g);
-        const f32x4 Y = load4<false>(s.a[1], g);
-        const f32x4 Z = load4<false>(s.a[2], g);
+        f32x4 V[6];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) lds_rank_add(lds_hist, tile_key(U, T, X[k], Y[k], Z[k]), true);
+        for (int c = 0; c < 6; ++c) V[c] = load4<false>(s.a[c], g);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            lds_rank_add(lds_hist, tile_key(U, T, V[0][k], V[1][k], V[2][k], V[3][k], V[4][k], V[5][k]), true);
     }
     const unsigned long long tail = n_groups * 4ull + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < 3 && tail < n)
-        atomicAdd(&lds_hist[tile_key(U, T, s.a[0][tail], s.a[1][tail], s.a[2][tail])], 1u);
+        atomicAdd(&lds_hist[tile_key(U, T, s.a[0][tail], s.a[1][tail], s.a[2][tail], s.a[3][tail], s.a[4][tail], s.a[5][tail])], 1u);
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) {
         const uint32_t c = lds_hist[b];
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(kStreamThreads) void reorder_scatter_kernel(Reorder
     const int live_in = full ? 4 : (is_tail ? 1 : 0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {   // every lane takes part: lds_rank_add is a wave-wide operation
-        key[k] = k < live_in ? tile_key(U, T, V[0][k], V[1][k], V[2][k]) : 0u;
+        key[k] = k < live_in ? tile_key(U, T, V[0][k], V[1][k], V[2][k], V[3][k], V[4][k], V[5][k]) : 0u;
         rank[k] = lds_rank_add(count, key[k], k < live_in);
     }
     __syncthreads();
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(kStreamThreads) void reorder_scatter_kernel(Reorder
     for (int k = 0; k < 4; ++k) {
         if (k < live) {
             const uint32_t d = count[key[k]] + rank[k];
+            if (d >= a.n) continue;   // cannot happen while histogram and keys agree; never write out of bounds
 #pragma unroll
             for (int c = 0; c < 6; ++c) a.dst[c][d] = V[c][k];
             a.dst_ty[d] = (uint8_t)((t4 >> (8 * k)) & 0xFFu);
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(kStreamThreads) void step_scatter_kernel(StepScatte
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {   // every lane takes part: lds_rank_add is a wave-wide operation
-        key[k] = k < live ? tile_key(U, T, V[0][k], V[1][k], V[2][k]) : 0u;
+        key[k] = k < live ? tile_key(U, T, V[0][k], V[1][k], V[2][k], V[3][k], V[4][k], V[5][k]) : 0u;
         rank[k] = lds_rank_add(count, key[k], k < live);
     }
 #pragma unroll
@@ -224,6 +226,7 @@ __global__ __launch_bounds__(kStreamThreads) void step_scatter_kernel(StepScatte
     for (int k = 0; k < 4; ++k) {
         if (k < live) {
             const uint32_t d = count[key[k]] + rank[k];
+            if (d >= a.n) continue;   // cannot happen while histogram and keys agree; never write out of bounds
 #pragma unroll
             for (int c = 0; c < 6; ++c) a.dst[c][d] = V[c][k];
             a.dst_ty[d] = (uint8_t)((t4 >> (8 * k)) & 0xFFu);

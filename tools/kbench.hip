@@ -15,7 +15,7 @@ using namespace pcl;
 
 // G = float4 groups per lane per array (particles per lane = 4*G)
 // GPOL: cache-policy bits of the field fetch (buffer_load aux: 1 = sc0, 2 = nt, 16 = sc1); -1 = plain global_load
-template <int G, bool NT_LD, bool NT_ST, bool PERSIST, bool GATHER, int BLOCK, int GPOL = -1>
+template <int G, bool NT_LD, bool NT_ST, bool PERSIST, bool GATHER, int BLOCK, int GPOL = -1, bool XCD = false>
 __global__ __launch_bounds__(BLOCK) void variant_kernel(StreamArgs a, StepUniforms U)
 {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -23,7 +23,9 @@ __global__ __launch_bounds__(BLOCK) void variant_kernel(StreamArgs a, StepUnifor
     const unsigned long long n_groups = a.n / 4ull;  // n is a multiple of 4*G*BLOCK here
     const unsigned long long tile = (unsigned long long)BLOCK * G;
     const unsigned long long n_tiles = n_groups / tile;
-    for (unsigned long long t = blockIdx.x; t < n_tiles; t += PERSIST ? gridDim.x : n_tiles) {
+    // XCD: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD one contiguous eighth of the tiles
+    const unsigned long long first_tile = XCD ? (unsigned long long)(blockIdx.x & 7u) * (n_tiles >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    for (unsigned long long t = first_tile; t < n_tiles; t += PERSIST ? gridDim.x : n_tiles) {
         f32x4 X[G], Y[G], Z[G], VX[G], VY[G], VZ[G];
         uint32_t T[G];
 #pragma unroll
@@ -289,19 +291,24 @@ int main(int argc, char** argv)
     }
     if (set == 2) {
         const unsigned tile_cells = argc > 6 ? atoi(argv[6]) : 16;
-        hipLaunchKernelGGL(generate_sorted_kernel, dim3(4096), dim3(256), 0, 0, c.s0, c.ty, c.n, side, tile_cells, r);
-        CK(hipDeviceSynchronize());
-        const unsigned grid = (unsigned)(c.n / 4ull / 256ull);
-        printf("sorted by %ux%u-cell tiles; per-step time as the order decays\n", tile_cells, tile_cells);
-        for (int k = 0; k < 129; ++k) {
-            StreamArgs& a = (k & 1) ? c.bwd : c.fwd;
-            CK(hipEventRecord(c.e0));
-            hipLaunchKernelGGL((variant_kernel<1, true, true, false, true, 256, -1>), dim3(grid), dim3(256), 0, 0, a, c.U);
-            CK(hipEventRecord(c.e1));
-            CK(hipEventSynchronize(c.e1));
-            float ms = 0;
-            CK(hipEventElapsedTime(&ms, c.e0, c.e1));
-            if (k < 4 || (k & (k - 1)) == 0 || k % 16 == 0) printf("step %3d: %8.4f ms  %8.1f GB/s %7.2f Gp/s\n", k, ms, c.n * 49.0 / ms / 1e6, c.n / ms / 1e6);
+        for (int variant = 0; variant < 3; ++variant) {
+            hipLaunchKernelGGL(generate_sorted_kernel, dim3(4096), dim3(256), 0, 0, c.s0, c.ty, c.n, side, tile_cells, r);
+            CK(hipDeviceSynchronize());
+            const int block = variant == 0 ? 512 : (variant == 1 ? 512 : 1024);
+            const unsigned grid = (unsigned)(c.n / 4ull / block);
+            printf("sorted by %ux%u-cell tiles, block %d xcd-remap %d; per-step time as the order decays\n", tile_cells, tile_cells, block, variant >= 1);
+            for (int k = 0; k < 17; ++k) {
+                StreamArgs& a = (k & 1) ? c.bwd : c.fwd;
+                CK(hipEventRecord(c.e0));
+                if (variant == 0) hipLaunchKernelGGL((variant_kernel<1, true, true, false, true, 512, -1, false>), dim3(grid), dim3(512), 0, 0, a, c.U);
+                else if (variant == 1) hipLaunchKernelGGL((variant_kernel<1, true, true, false, true, 512, -1, true>), dim3(grid), dim3(512), 0, 0, a, c.U);
+                else hipLaunchKernelGGL((variant_kernel<1, true, true, false, true, 1024, -1, true>), dim3(grid), dim3(1024), 0, 0, a, c.U);
+                CK(hipEventRecord(c.e1));
+                CK(hipEventSynchronize(c.e1));
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, c.e0, c.e1));
+                if (k < 5 || k == 8 || k == 16) printf("step %3d: %8.4f ms  %8.1f GB/s %7.2f Gp/s\n", k, ms, c.n * 49.0 / ms / 1e6, c.n / ms / 1e6);
+            }
         }
     }
     return 0;
