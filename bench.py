@@ -115,6 +115,11 @@ def main():
     ap.add_argument("--grid-blocks", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--edits", action="store_true",
+                    help="every step a brush (src/cursor.rs, Shift mode) rewrites the cells within falloff_dist of a "
+                         "moving cursor; the dirty list is broadcast and patched before the step")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="use the RCCL broadcast/all-reduce path even with one rank (when started by torch.distributed.run)")
     args = ap.parse_args()
 
     import torch
@@ -129,7 +134,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or (args.force_collectives and "RANK" in os.environ):
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     dims = tuple(args.field)
@@ -141,7 +146,8 @@ def main():
     # every rank fills its own index range with the seeded scene on the device.
     field_host = swirl_field(*dims, RADIUS, args.seed) if rank == 0 else None
     sc = pa.ShardedCompute.new(None, field_host, n_total=n_local * world, seed=args.seed,
-                               pos_extent=args.pos_extent, vel_extent=10.0, device=local_rank)
+                               pos_extent=args.pos_extent, vel_extent=10.0, device=local_rank,
+                               force_collectives=args.force_collectives)
     assert sc.num_local_particles == n_local
     c = sc.local
     c.set_tuning(args.grid_blocks, args.variant)
@@ -150,13 +156,30 @@ def main():
     diag_on = args.diagnostics == "on"
     sc.enable_step_diagnostics(diag_on)
 
+    brush = grid_host = None
+    if args.edits:
+        # rank 0 owns the host copy of the field and the brush, like the reference's App
+        # (src/main.rs:287-316); the other ranks only receive the dirty cells
+        if rank == 0:
+            grid_host = pa.Grid(field_host[:, :3], dims, pa.Bounds((-RADIUS,) * 3, (2 * RADIUS,) * 3))
+            brush = pa.Brush(pa.EditMode(mode="shift", falloff_dist=1.0, strength=1.0))
+            brush.mouse_down(grid_host, (0.0, 0.0, 0.0))
+    frame = [0]
+
     def one_step():
+        if args.edits:
+            idx = cells = None
+            if rank == 0:
+                a = 0.05 * frame[0]
+                idx, cells = brush.mouse_moved(grid_host, (0.3 * np.cos(a), 0.3 * np.sin(a), 0.0))
+            sc.patch_force_grid_indexed(idx, cells)
+            frame[0] += 1
         sc.compute()          # one update of the local range (+ the diagnostics all-reduce when enabled)
 
     def fence():
         sc.wait()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -172,7 +195,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
@@ -205,6 +228,7 @@ def main():
                 "field_dims": list(dims),
                 "pos_extent": args.pos_extent,
                 "diagnostics_per_step": diag_on,
+                "field_edits_per_step": bool(args.edits),
                 "reorder_interval": args.reorder_interval,
                 "reorder_passes_in_timed_region": c.reorder_count - reorders0,
                 "parallelism": f"particle-sharded x{world}, field replicated by RCCL broadcast",
@@ -230,7 +254,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     sc.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -155,6 +155,16 @@ int pcl_patch_force_grid(pcl_compute* h, size_t first_cell,
 int pcl_patch_force_grid_device(pcl_compute* h, size_t first_cell,
                                 const void* dev_cells, size_t count);
 
+/* Brush edit of a list of cells: field[cell_indices[i]] = cells[i].  Replaces
+ * the write loop of Cursor::mouse_moved, src/cursor.rs:84-101 (grid.grid[ix]
+ * for ix in modify_vector_indices) followed by the whole-field re-upload of
+ * src/main.rs:371-380.  The _device form takes both lists from device memory
+ * (u32 indices; out-of-range indices are skipped) and is ordered on the stream. */
+int pcl_patch_force_grid_indexed(pcl_compute* h, const uint32_t* cell_indices,
+                                 const float (*cells)[4], size_t count);
+int pcl_patch_force_grid_indexed_device(pcl_compute* h, const void* dev_cell_indices,
+                                        const void* dev_cells, size_t count);
+
 /* Replaces Compute::update_sim_params, src/compute.rs:206-219.  delta_t
  * travels in the block, as in the reference. */
 int pcl_update_sim_params(pcl_compute* h, const pcl_sim_params* params);

@@ -53,6 +53,8 @@ SIGNATURES = {
     "pcl_update_force_grid_device": (_i, [_vp, _vp, _sz]),
     "pcl_patch_force_grid": (_i, [_vp, _sz, _vp, _sz]),
     "pcl_patch_force_grid_device": (_i, [_vp, _sz, _vp, _sz]),
+    "pcl_patch_force_grid_indexed": (_i, [_vp, _vp, _vp, _sz]),
+    "pcl_patch_force_grid_indexed_device": (_i, [_vp, _vp, _vp, _sz]),
     "pcl_update_sim_params": (_i, [_vp, _vp]),
     "pcl_step": (_i, [_vp]),
     "pcl_step_dt": (_i, [_vp, _f]),

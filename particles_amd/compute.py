@@ -107,6 +107,18 @@ class Compute:
         g = _as_cells(cells)
         _lib.check(self._lib.pcl_patch_force_grid(self._h, int(first_cell), _ptr(g), g.shape[0]))
 
+    def patch_force_grid_indexed(self, cell_indices, cells):
+        """field[cell_indices[i]] = cells[i] (brush edit of a list of cells)."""
+        idx = np.ascontiguousarray(cell_indices, dtype=np.uint32).reshape(-1)
+        g = _as_cells(cells)
+        if idx.shape[0] != g.shape[0]:
+            raise ValueError("cell_indices and cells must have the same length")
+        _lib.check(self._lib.pcl_patch_force_grid_indexed(self._h, _ptr(idx), _ptr(g), idx.shape[0]))
+
+    def patch_force_grid_indexed_device(self, dev_indices, dev_cells, count):
+        _lib.check(self._lib.pcl_patch_force_grid_indexed_device(
+            self._h, C.c_void_p(int(dev_indices)), C.c_void_p(int(dev_cells)), int(count)))
+
     def update_force_grid_device(self, dev_ptr, n_cells):
         _lib.check(self._lib.pcl_update_force_grid_device(self._h, C.c_void_p(int(dev_ptr)), int(n_cells)))
 

@@ -881,6 +881,45 @@ int pcl_patch_force_grid_device(pcl_compute* h, size_t first_cell, const void* d
     return upload_field(h, first_cell, dev_cells, count, true);
 }
 
+int pcl_patch_force_grid_indexed(pcl_compute* h, const uint32_t* cell_indices, const float (*cells)[4], size_t count)
+{
+    if (int rc = bind(h)) return rc;
+    if (count == 0) return PCL_OK;
+    PCL_REQUIRE(cell_indices != nullptr && cells != nullptr, "pcl_patch_force_grid_indexed: null argument");
+    for (size_t i = 0; i < count; ++i)
+        if (cell_indices[i] >= h->n_cells)
+            return fail(PCL_ERR_OUT_OF_RANGE, "pcl_patch_force_grid_indexed: cell index " +
+                                                  std::to_string(cell_indices[i]) + " is outside the field");
+    char* staging = nullptr;
+    PCL_HIP_TRY(hipMalloc((void**)&staging, count * (sizeof(pcl::f32x4) + sizeof(uint32_t))));
+    pcl::f32x4* d_cells = reinterpret_cast<pcl::f32x4*>(staging);
+    uint32_t* d_index = reinterpret_cast<uint32_t*>(staging + count * sizeof(pcl::f32x4));
+    hipError_t e = hipMemcpyAsync(d_cells, cells, count * sizeof(pcl::f32x4), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_index, cell_indices, count * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pcl::patch_field_kernel, dim3(linear_grid(h, count)), dim3(pcl::kBlockThreads), 0, h->stream,
+                           h->field, (unsigned long long)h->n_cells, (const uint32_t*)d_index,
+                           (const pcl::f32x4*)d_cells, (unsigned long long)count);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(staging);
+    if (e != hipSuccess) return fail(PCL_ERR_HIP, std::string("pcl_patch_force_grid_indexed: ") + hipGetErrorString(e));
+    return PCL_OK;
+}
+
+int pcl_patch_force_grid_indexed_device(pcl_compute* h, const void* dev_cell_indices, const void* dev_cells, size_t count)
+{
+    if (int rc = bind(h)) return rc;
+    if (count == 0) return PCL_OK;
+    PCL_REQUIRE(dev_cell_indices != nullptr && dev_cells != nullptr, "pcl_patch_force_grid_indexed_device: null argument");
+    hipLaunchKernelGGL(pcl::patch_field_kernel, dim3(linear_grid(h, count)), dim3(pcl::kBlockThreads), 0, h->stream,
+                       h->field, (unsigned long long)h->n_cells, reinterpret_cast<const uint32_t*>(dev_cell_indices),
+                       reinterpret_cast<const pcl::f32x4*>(dev_cells), (unsigned long long)count);
+    PCL_HIP_TRY(hipGetLastError());
+    return PCL_OK;
+}
+
 int pcl_update_sim_params(pcl_compute* h, const pcl_sim_params* params)
 {
     if (!h) return fail(PCL_ERR_INVALID, "null handle");

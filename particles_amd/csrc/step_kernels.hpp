@@ -628,6 +628,22 @@ __global__ __launch_bounds__(kBlockThreads) void cell_index_kernel(
     }
 }
 
+// ------------------------------------------------ indexed field patch K5
+
+// field[index[i]] = cells[i]: brush edits rewrite a list of cells
+// (src/cursor.rs:79-103 writes grid.grid[ix] for ix in modify_vector_indices).
+__global__ __launch_bounds__(kBlockThreads) void patch_field_kernel(
+    f32x4* __restrict__ field, unsigned long long n_cells, const uint32_t* __restrict__ index,
+    const f32x4* __restrict__ cells, unsigned long long count)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x;
+         i < count; i += stride) {
+        const uint32_t c = index[i];
+        if (c < n_cells) field[c] = cells[i];
+    }
+}
+
 // --------------------------------------------- seeded synthetic scene
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long z)

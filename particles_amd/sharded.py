@@ -30,11 +30,13 @@ def shard_range(n_total, rank, world_size):
 
 class ShardedCompute:
     def __init__(self, particles, force_grid, *, process_group=None, device=None, compute_cls=Compute,
-                 n_total=None, seed=None, pos_extent=2.0, vel_extent=10.0):
+                 n_total=None, seed=None, pos_extent=2.0, vel_extent=10.0, force_collectives=False):
         """Every rank passes the full ``particles`` array and keeps its own
         range, or passes ``particles=None`` with ``n_total`` and ``seed`` to
         fill its range with the seeded synthetic scene on the device.
         ``force_grid`` is taken from rank 0 (other ranks may pass ``None``).
+        ``force_collectives`` runs the broadcast / all-reduce code path even
+        in a one-rank group (to exercise RCCL on a single GPU).
         """
         import torch
         import torch.distributed as dist
@@ -49,6 +51,8 @@ class ShardedCompute:
             device = torch.cuda.current_device() if self.on_gpu else 0
         self.device = int(device)
         self._comm_device = torch.device("cuda", self.device) if self.on_gpu else torch.device("cpu")
+        # collectives are skipped only when there is nobody to talk to
+        self._collectives = dist.is_initialized() and (self.world_size > 1 or force_collectives)
 
         if particles is not None:
             particles = np.ascontiguousarray(particles).reshape(-1)
@@ -61,7 +65,7 @@ class ShardedCompute:
 
         grid = self._replicate_field(force_grid, 0, None)
         local = particles[self.first:self.last] if particles is not None else np.zeros(0, dtype=PARTICLE_DTYPE)
-        if self.on_gpu and self.world_size > 1:
+        if self.on_gpu and self._collectives:
             # the replicated field is already on this device: adopt it without a host round trip
             self.local = compute_cls.new(local, np.zeros((1, 4), dtype=np.float32), device=self.device)
             self.local.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -89,7 +93,7 @@ class ShardedCompute:
         """Broadcast rank 0's cells [first_cell, first_cell+count) (count=None:
         the whole array) and return them as a host array on every rank."""
         torch, dist = self._torch, self._dist
-        if self.world_size == 1:
+        if not self._collectives:
             return np.ascontiguousarray(cells, dtype=np.float32)
         header = [None]
         if self.rank == 0:
@@ -108,7 +112,7 @@ class ShardedCompute:
     def update_force_grid(self, force_grid):
         """Whole-field replace (src/compute.rs:198-204) from rank 0's array."""
         g = self._replicate_field(force_grid, 0, None)
-        if self.on_gpu and self.world_size > 1:
+        if self.on_gpu and self._collectives:
             self.local.update_force_grid_device(g.data_ptr(), g.shape[0])
         else:
             self.local.update_force_grid(g)
@@ -116,11 +120,40 @@ class ShardedCompute:
     def patch_force_grid(self, first_cell, cells):
         """Brush edit: only cells [first_cell, first_cell+len) travel."""
         g = self._replicate_field(cells, first_cell, None)
-        first_cell = first_cell if self.world_size == 1 else self._last_first_cell
-        if self.on_gpu and self.world_size > 1:
+        first_cell = first_cell if not self._collectives else self._last_first_cell
+        if self.on_gpu and self._collectives:
             self.local.patch_force_grid_device(first_cell, g.data_ptr(), g.shape[0])
         else:
             self.local.patch_force_grid(first_cell, g)
+
+    def patch_force_grid_indexed(self, cell_indices, cells):
+        """Brush edit of a list of cells (src/cursor.rs:84-101): rank 0's
+        ``(cell_indices, cells)`` lists are broadcast and applied everywhere."""
+        torch, dist = self._torch, self._dist
+        if not self._collectives:
+            self.local.patch_force_grid_indexed(cell_indices, cells)
+            return
+        header = [None]
+        if self.rank == 0:
+            cell_indices = np.ascontiguousarray(cell_indices, dtype=np.uint32).reshape(-1)
+            cells = np.ascontiguousarray(cells, dtype=np.float32).reshape(-1, 4)
+            header = [int(cell_indices.shape[0])]
+        dist.broadcast_object_list(header, src=0, group=self.group)
+        n = header[0]
+        if n == 0:
+            return
+        # one message: n cells of 16 bytes followed by n 4-byte indices
+        buf = torch.empty(n * 5, dtype=torch.int32, device=self._comm_device)
+        if self.rank == 0:
+            packed = np.concatenate([cells.view(np.int32).reshape(-1), cell_indices.view(np.int32)])
+            buf.copy_(torch.from_numpy(packed))
+        dist.broadcast(buf, src=0, group=self.group)
+        if self.on_gpu:
+            self._last_field_tensor = buf
+            self.local.patch_force_grid_indexed_device(buf[n * 4:].data_ptr(), buf.data_ptr(), n)
+        else:
+            host = buf.numpy()
+            self.local.patch_force_grid_indexed(host[n * 4:].view(np.uint32), host[:n * 4].view(np.float32).reshape(n, 4))
 
     # -- parameters and stepping -----------------------------------------
     def update_sim_params(self, sim_params):
@@ -168,7 +201,7 @@ class ShardedCompute:
     def _start_diag_allreduce(self):
         torch, dist = self._torch, self._dist
         self._fill_diag_buf()
-        if self.world_size > 1:
+        if self._collectives:
             sums = self._diag_buf[:16].view(torch.float64)     # count, kinetic energy
             maxs = self._diag_buf[16:40].view(torch.float32)   # max xyz, -min xyz
             self._pending.append(dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -220,7 +253,7 @@ class ShardedCompute:
     def gather_particles(self):
         """The full set in caller order on every rank (small sets / tests)."""
         mine = self.read_local()
-        if self.world_size == 1:
+        if not self._collectives:
             return mine
         parts = [None] * self.world_size
         self._dist.all_gather_object(parts, mine, group=self.group)

@@ -39,6 +39,12 @@ class OracleCompute:
             raise pa.PclError(-4, "range outside [0, n)")
         self.g[first_cell:first_cell + cells.shape[0]] = cells
 
+    def patch_force_grid_indexed(self, cell_indices, cells):
+        idx = np.ascontiguousarray(cell_indices, dtype=np.uint32)
+        if idx.size and idx.max() >= self.g.shape[0]:
+            raise pa.PclError(-4, "cell index outside the field")
+        self.g[idx] = np.ascontiguousarray(cells, dtype=np.float32)
+
     def update_sim_params(self, sp):
         self.sp = sp.copy()
 

@@ -52,6 +52,11 @@ def _worker(rank, world, port, out_dir):
         patch = np.full((50, 4), 2.5, dtype=np.float32)
         sc.patch_force_grid(400, patch if rank == 0 else None)
         sc.compute()
+        # brush-style list of cells, also from rank 0 only
+        idx = np.array([7, 999, 123], dtype=np.uint32)
+        vals = np.array([[1, 2, 3, 1], [4, 5, 6, 1], [7, 8, 9, 1]], dtype=np.float32)
+        sc.patch_force_grid_indexed(idx if rank == 0 else None, vals if rank == 0 else None)
+        sc.compute()
         full = sc.gather_particles()
         diag = sc.diagnostics()
         # a whole-field replace and a device-generated shard
@@ -82,6 +87,8 @@ def test_two_rank_sharding_matches_unsharded(tmp_path, oracle):
     want = oracle.run(sp, p, g, 3, mode=oracle.MODE_SKIP_INERT)
     g2 = g.copy()
     g2[400:450] = 2.5
+    want = oracle.run(sp, want, g2, 1, mode=oracle.MODE_SKIP_INERT)
+    g2[[7, 999, 123]] = np.array([[1, 2, 3, 1], [4, 5, 6, 1], [7, 8, 9, 1]], dtype=np.float32)
     want = oracle.run(sp, want, g2, 1, mode=oracle.MODE_SKIP_INERT)
     want_diag = oracle.diagnostics(sp, want)
     want2 = oracle.run(sp, want, g, 1, mode=oracle.MODE_SKIP_INERT)
