@@ -464,7 +464,7 @@ int do_reorder(pcl_compute* h)
     uint32_t grid = 0;
     if (int rc = reorder_prepare(h, T, &a, &grid)) return rc;
     hipLaunchKernelGGL(pcl::reorder_scatter_kernel, dim3(grid), dim3(pcl::kStreamThreads),
-                       (size_t)T.n_bins * sizeof(uint32_t), h->stream, a, U, T);
+                       pcl::scatter_lds_bytes(T.n_bins), h->stream, a, U, T);
     PCL_HIP_TRY(hipGetLastError());
     reorder_commit(h);
     h->steps_since_sort = 0;
@@ -541,7 +541,7 @@ int do_step(pcl_compute* h)
                 if (int rc = reserve_partials(h, grid)) return rc;
             sa.field = h->field;
             sa.partials = h->d_partials;
-            const size_t lds_bytes = (size_t)T.n_bins * sizeof(uint32_t);
+            const size_t lds_bytes = pcl::scatter_lds_bytes(T.n_bins);
             if (h->step_diag)
                 hipLaunchKernelGGL((pcl::step_scatter_kernel<true>), dim3(grid), dim3(pcl::kStreamThreads), lds_bytes,
                                    h->stream, sa, U, T);

@@ -92,14 +92,179 @@ struct ReorderArgs {
     unsigned long long n;
 };
 
+// LDS plan of the scatter kernels (dynamic shared memory), B = number of bins:
+//   u32 slot[B]      per-bin particle count of this tile, then (bin's reserved
+//                    global base) - (bin's first local position)
+//   u16 lstart[B]    first local position of the bin inside the tile
+//   u32 dest[2048]   global slot of every local position
+//   u32 stage[2][2048], u8 stage_ty[2048]   one array at a time, regrouped
+// The tile's particles are regrouped by bin in LDS so that consecutive lanes
+// write consecutive slots: a tile whose particles fall into k bins issues k
+// contiguous runs per array instead of 2048 scattered elements.
+__host__ __device__ constexpr size_t scatter_lds_bytes(uint32_t n_bins)
+{
+    return (size_t)n_bins * 6u + (size_t)kStreamTile * 4u * 3u + (size_t)kStreamTile;
+}
+
+struct ScatterLds {
+    uint32_t* slot;
+    uint16_t* lstart;
+    uint32_t* dest;
+    uint32_t* stage[2];
+    uint8_t* stage_ty;
+    __device__ __forceinline__ ScatterLds(unsigned char* base, uint32_t n_bins)
+    {
+        slot = reinterpret_cast<uint32_t*>(base);
+        dest = slot + n_bins;
+        stage[0] = dest + kStreamTile;
+        stage[1] = stage[0] + kStreamTile;
+        lstart = reinterpret_cast<uint16_t*>(stage[1] + kStreamTile);
+        stage_ty = reinterpret_cast<uint8_t*>(lstart + n_bins);
+    }
+};
+
+// After every thread has added its particles to slot[] (lds_rank_add): turn the
+// per-bin counts into local start positions, reserve each non-empty bin's run of
+// global slots with one atomic add, and leave in slot[b] the offset that maps a
+// local position of bin b to its global slot.  Ends with a barrier.
+__device__ __forceinline__ void scatter_plan(const ScatterLds& L, uint32_t n_bins, uint32_t* __restrict__ cursor)
+{
+    __shared__ uint32_t wave_total[kStreamThreads / 64];
+    const uint32_t per = (n_bins + kStreamThreads - 1) / kStreamThreads;
+    const uint32_t b0 = threadIdx.x * per;
+    uint32_t sum = 0u;
+    for (uint32_t i = 0; i < per; ++i)
+        if (b0 + i < n_bins) sum += L.slot[b0 + i];
+    // block-wide exclusive scan of `sum`
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += wave_total[w];
+    for (uint32_t i = 0; i < per; ++i) {
+        const uint32_t b = b0 + i;
+        if (b < n_bins) {
+            const uint32_t c = L.slot[b];
+            L.lstart[b] = (uint16_t)run;
+            if (c) L.slot[b] = atomicAdd(&cursor[b], c) - run;
+            run += c;
+        }
+    }
+    __syncthreads();
+}
+
+// Regroup one per-particle value through LDS and write it out: every thread
+// deposits its `live` values at their local positions, then lane t writes the
+// values of local positions t, t+512, ... to their global slots.
+template <typename T>
+__device__ __forceinline__ void scatter_array(uint32_t* stage, const uint32_t lpos[4], const T val[4], int live,
+                                              const uint32_t out_slot[4], uint32_t n_local, T* __restrict__ dst)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < live) stage[lpos[k]] = __builtin_bit_cast(uint32_t, val[k]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t l = threadIdx.x + (uint32_t)i * kStreamThreads;
+        if (l < n_local) dst[out_slot[i]] = __builtin_bit_cast(T, stage[l]);
+    }
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void scatter_load(const ReorderArgs& a, unsigned long long g, unsigned long long tail,
+                                             bool full, bool is_tail, f32x4 V[6], uint32_t& t4, uint32_t orig[4])
+{
+    if (full) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) V[c] = load4<true>(a.src[c], g);
+        t4 = reinterpret_cast<const uint32_t*>(a.src_ty)[g];
+        if (a.src_orig) {
+            const u32x4 o = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.src_orig) + g);
+            orig[0] = o.x; orig[1] = o.y; orig[2] = o.z; orig[3] = o.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) orig[k] = (uint32_t)(g * 4ull + k);
+        }
+    } else if (is_tail) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) V[c][0] = a.src[c][tail];
+        t4 = a.src_ty[tail];
+        orig[0] = a.src_orig ? a.src_orig[tail] : (uint32_t)tail;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) V[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// Plans the tile (scatter_plan) and writes state, type and caller index of the
+// thread's `live` particles to their slots, one array at a time through LDS.
+__device__ __forceinline__ void scatter_write(const ReorderArgs& a, const ScatterLds& L, uint32_t n_bins,
+                                              const f32x4 V[6], uint32_t t4, const uint32_t orig[4],
+                                              const uint32_t key[4], const uint32_t rank[4], int live)
+{
+    __shared__ uint32_t n_local_sh;
+    scatter_plan(L, n_bins, a.cursor);
+    uint32_t lpos[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        lpos[k] = 0u;
+        if (k < live) {
+            lpos[k] = (uint32_t)L.lstart[key[k]] + rank[k];
+            L.dest[lpos[k]] = L.slot[key[k]] + lpos[k];
+        }
+    }
+    // number of particles in this tile (2048 except in the last blocks)
+    const unsigned long long first = (unsigned long long)blockIdx.x * kStreamTile;
+    const unsigned long long n_groups = a.n / 4ull;
+    if (threadIdx.x == 0) {
+        unsigned long long cnt = 0;
+        if (first < n_groups * 4ull) cnt = (n_groups * 4ull - first < (unsigned long long)kStreamTile) ? n_groups * 4ull - first : kStreamTile;
+        else cnt = a.n - n_groups * 4ull;   // the appended tail block
+        n_local_sh = (uint32_t)cnt;
+    }
+    __syncthreads();
+    const uint32_t n_local = n_local_sh;
+    uint32_t out_slot[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t l = threadIdx.x + (uint32_t)i * kStreamThreads;
+        // a slot >= n cannot happen while histogram and keys agree; never write out of bounds
+        out_slot[i] = l < n_local ? L.dest[l] : 0u;
+        if (out_slot[i] >= a.n) out_slot[i] = (uint32_t)(a.n - 1);
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const float val[4] = {V[c][0], V[c][1], V[c][2], V[c][3]};
+        scatter_array<float>(L.stage[c & 1], lpos, val, live, out_slot, n_local, a.dst[c]);
+    }
+    scatter_array<uint32_t>(L.stage[0], lpos, orig, live, out_slot, n_local, a.dst_orig);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < live) L.stage_ty[lpos[k]] = (uint8_t)((t4 >> (8 * k)) & 0xFFu);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t l = threadIdx.x + (uint32_t)i * kStreamThreads;
+        if (l < n_local) a.dst_ty[out_slot[i]] = L.stage_ty[l];
+    }
+}
+
 // One tile of 2048 consecutive source particles per block (plus one block for
 // the ragged tail when n is not a multiple of 4).
 __global__ __launch_bounds__(kStreamThreads) void reorder_scatter_kernel(ReorderArgs a, StepUniforms U,
                                                                          TileMap T)
 {
-    extern __shared__ uint32_t lds[];
-    uint32_t* count = lds;               // particles of this tile per bin, then the bin's base slot
-    for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) count[b] = 0u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const ScatterLds L(lds_raw, T.n_bins);
+    for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) L.slot[b] = 0u;
     __syncthreads();
 
     const unsigned long long n_groups = a.n / 4ull;
@@ -109,45 +274,19 @@ __global__ __launch_bounds__(kStreamThreads) void reorder_scatter_kernel(Reorder
     // that holds no full group, and its lanes 0..2 carry them.
     const unsigned long long tail = n_groups * 4ull + threadIdx.x;
     const bool is_tail = !full && blockIdx.x == gridDim.x - 1 && threadIdx.x < 3 && tail < a.n;
+    const int live = full ? 4 : (is_tail ? 1 : 0);
 
     f32x4 V[6];
-    uint32_t t4 = 0u, key[4], rank[4], orig[4];
-    if (full) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) V[c] = load4<true>(a.src[c], g);
-        t4 = reinterpret_cast<const uint32_t*>(a.src_ty)[g];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) orig[k] = a.src_orig ? a.src_orig[g * 4ull + k] : (uint32_t)(g * 4ull + k);
-    } else if (is_tail) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) V[c][0] = a.src[c][tail];
-        t4 = a.src_ty[tail];
-        orig[0] = a.src_orig ? a.src_orig[tail] : (uint32_t)tail;
-    }
-    const int live_in = full ? 4 : (is_tail ? 1 : 0);
+    uint32_t t4 = 0u, orig[4] = {0u, 0u, 0u, 0u};
+    scatter_load(a, g, tail, full, is_tail, V, t4, orig);
+    uint32_t key[4], rank[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {   // every lane takes part: lds_rank_add is a wave-wide operation
-        key[k] = k < live_in ? tile_key(U, T, V[0][k], V[1][k], V[2][k], V[3][k], V[4][k], V[5][k]) : 0u;
-        rank[k] = lds_rank_add(count, key[k], k < live_in);
+        key[k] = k < live ? tile_key(U, T, V[0][k], V[1][k], V[2][k], V[3][k], V[4][k], V[5][k]) : 0u;
+        rank[k] = lds_rank_add(L.slot, key[k], k < live);
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) {
-        const uint32_t c = count[b];
-        if (c) count[b] = atomicAdd(&a.cursor[b], c);
-    }
-    __syncthreads();
-    const int live = full ? 4 : (is_tail ? 1 : 0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (k < live) {
-            const uint32_t d = count[key[k]] + rank[k];
-            if (d >= a.n) continue;   // cannot happen while histogram and keys agree; never write out of bounds
-#pragma unroll
-            for (int c = 0; c < 6; ++c) a.dst[c][d] = V[c][k];
-            a.dst_ty[d] = (uint8_t)((t4 >> (8 * k)) & 0xFFu);
-            a.dst_orig[d] = orig[k];
-        }
-    }
+    scatter_write(a, L, T.n_bins, V, t4, orig, key, rank, live);
 }
 
 // The update and the scatter in one pass: every particle is advanced one step
@@ -165,9 +304,9 @@ template <bool DIAG>
 __global__ __launch_bounds__(kStreamThreads) void step_scatter_kernel(StepScatterArgs sa, StepUniforms U, TileMap T)
 {
     const ReorderArgs& a = sa.r;
-    extern __shared__ uint32_t lds[];
-    uint32_t* count = lds;
-    for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) count[b] = 0u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const ScatterLds L(lds_raw, T.n_bins);
+    for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) L.slot[b] = 0u;
     __syncthreads();
 
     const unsigned long long n_groups = a.n / 4ull;
@@ -181,29 +320,13 @@ __global__ __launch_bounds__(kStreamThreads) void step_scatter_kernel(StepScatte
     if (DIAG) acc.init();
 
     f32x4 V[6];
-    uint32_t t4 = 0u, key[4], rank[4], orig[4];
-    if (full) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) V[c] = load4<true>(a.src[c], g);
-        t4 = reinterpret_cast<const uint32_t*>(a.src_ty)[g];
-        if (a.src_orig) {
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 o = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.src_orig) + g);
-            orig[0] = o.x; orig[1] = o.y; orig[2] = o.z; orig[3] = o.w;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) orig[k] = (uint32_t)(g * 4ull + k);
-        }
-    } else if (is_tail) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) V[c][0] = a.src[c][tail];
-        t4 = a.src_ty[tail];
-        orig[0] = a.src_orig ? a.src_orig[tail] : (uint32_t)tail;
-    }
+    uint32_t t4 = 0u, orig[4] = {0u, 0u, 0u, 0u};
+    scatter_load(a, g, tail, full, is_tail, V, t4, orig);
+    uint32_t key[4], rank[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {   // every lane takes part: lds_rank_add is a wave-wide operation
         key[k] = k < live ? tile_key(U, T, V[0][k], V[1][k], V[2][k], V[3][k], V[4][k], V[5][k]) : 0u;
-        rank[k] = lds_rank_add(count, key[k], k < live);
+        rank[k] = lds_rank_add(L.slot, key[k], k < live);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -217,22 +340,7 @@ __global__ __launch_bounds__(kStreamThreads) void step_scatter_kernel(StepScatte
         }
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) {
-        const uint32_t c = count[b];
-        if (c) count[b] = atomicAdd(&a.cursor[b], c);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (k < live) {
-            const uint32_t d = count[key[k]] + rank[k];
-            if (d >= a.n) continue;   // cannot happen while histogram and keys agree; never write out of bounds
-#pragma unroll
-            for (int c = 0; c < 6; ++c) a.dst[c][d] = V[c][k];
-            a.dst_ty[d] = (uint8_t)((t4 >> (8 * k)) & 0xFFu);
-            a.dst_orig[d] = orig[k];
-        }
-    }
+    scatter_write(a, L, T.n_bins, V, t4, orig, key, rank, live);
     if (DIAG) block_reduce_store<kStreamThreads>(acc, sa.partials + blockIdx.x);
 }
 

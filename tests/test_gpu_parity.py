@@ -294,3 +294,69 @@ def test_cpp_host_mirror_matches_oracle(oracle, tmp_path):
     sp, p, g = default_scene()
     sp.delta_t = DT
     assert_particles_bit_equal(got, oracle.run(sp, p, g, 6), "C++ host mirror")
+
+
+@pytest.mark.parametrize("n", [1, 5, 7, 2051, 4100])
+def test_reorder_now_tiny_and_ragged_sets(oracle, n):
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = (32, 32, 4)
+    g = scene_swirl_field(32, 32, 4, 10.0, seed=1)
+    p = oracle.synth_particles(n, seed=3 * n, pos_extent=20.0, vel_extent=10.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        c.reorder_now()
+        assert c.reorder_count == 1
+        assert_particles_bit_equal(c.read_particles(), _with_unit_w(p), "reorder alone changes nothing")
+        c.compute()
+        c.reorder_now()
+        c.compute()
+        assert_particles_bit_equal(c.read_particles(), oracle.run(sp, p, g, 2, mode=oracle.MODE_SKIP_INERT), f"n={n}")
+
+
+def _with_unit_w(p):
+    q = np.array(p, copy=True).view(pa.PARTICLE_DTYPE)
+    q["pos"][:, 3] = 1.0
+    q["vel"][:, 3] = 1.0
+    q["_padd"] = 0
+    return q
+
+
+def test_reorder_3d_field_many_bins(oracle):
+    """128 x 128 x 64 cells: more tiles of 256 cells than bins, so tiles grow."""
+    dims = (128, 128, 64)
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = dims
+    rng = np.random.default_rng(11)
+    g = np.ones((dims[0] * dims[1] * dims[2], 4), dtype=np.float32)
+    g[:, :3] = rng.uniform(-1, 1, size=(g.shape[0], 3)).astype(np.float32)
+    n = 200001
+    p = oracle.synth_particles(n, seed=17, pos_extent=20.0, vel_extent=40.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        c.set_reorder_interval(2)
+        for _ in range(5):
+            c.compute()
+        assert c.reorder_count >= 2
+        assert_particles_bit_equal(c.read_particles(), oracle.run(sp, p, g, 5, mode=oracle.MODE_SKIP_INERT), "3-D field")
+
+
+def test_changing_dt_between_counting_and_scatter_steps(oracle):
+    """delta_t changes every frame in the reference (wall clock, src/main.rs:335-342);
+    the sort key's lookahead must not make a pending histogram inconsistent."""
+    sp = pa.SimParams()
+    sp.force_grid_dimensions = (64, 64, 1)
+    g = scene_swirl_field(64, 64, 1, 10.0, seed=2)
+    n = 50000
+    p = oracle.synth_particles(n, seed=23, pos_extent=20.0, vel_extent=10.0)
+    cur = p
+    with pa.Compute.new(p, g) as c:
+        c.set_reorder_interval(3)
+        for k in range(10):
+            sp.delta_t = np.float32(0.004 + 0.003 * k)
+            c.update_sim_params(sp)
+            c.compute()
+            cur = oracle.step(sp, cur, g, mode=oracle.MODE_SKIP_INERT)
+        assert c.reorder_count >= 3
+        assert_particles_bit_equal(c.read_particles(), cur, "per-frame dt")
