@@ -346,14 +346,15 @@ uint32_t floor_log2(uint32_t v)
 // Tiles of at most 256 cells (4 KiB of field), z extent first because z is the
 // fastest-varying cell coordinate; tiles grow until there are at most
 // kMaxReorderBins of them.
-pcl::TileMap make_tile_map(const pcl_sim_params& p, int interval)
+pcl::TileMap make_tile_map(const pcl_sim_params& p, int interval, uint32_t log2_tile_cells = 8)
 {
     const uint32_t d[3] = {std::max(1u, p.force_grid_dimensions[0]), std::max(1u, p.force_grid_dimensions[1]),
                            std::max(1u, p.force_grid_dimensions[2])};
     uint32_t sh[3];
-    sh[2] = std::min(4u, floor_log2(d[2]));
-    sh[1] = std::min(std::min(4u, 8u - sh[2]), floor_log2(d[1]));
-    sh[0] = std::min(8u - sh[2] - sh[1], floor_log2(d[0]));
+    const uint32_t lt = log2_tile_cells, half = (lt + 1u) / 2u;
+    sh[2] = std::min(half, floor_log2(d[2]));
+    sh[1] = std::min(std::min(half, lt - sh[2]), floor_log2(d[1]));
+    sh[0] = std::min(lt - sh[2] - sh[1], floor_log2(d[0]));
     auto tiles = [&](int a) { return (uint64_t)((d[a] + (1u << sh[a]) - 1u) >> sh[a]); };
     while (tiles(0) * tiles(1) * tiles(2) > pcl::kMaxReorderBins) {
         int grow = 0;
@@ -367,9 +368,18 @@ pcl::TileMap make_tile_map(const pcl_sim_params& p, int interval)
     T.ntz = (uint32_t)tiles(2);
     T.n_bins = (uint32_t)(tiles(0) * tiles(1) * tiles(2));
     for (int a = 0; a < 3; ++a) T.max_ix[a] = d[a] - 1u;
+    const float side = p.bounding_volume_radius * 2.0f;
+    for (int a = 0; a < 3; ++a) T.inv_cell[a] = (side > 0.0f && std::isfinite(side)) ? (float)d[a] / side : 0.0f;
     // aim the order at the middle of the refresh interval
     T.lookahead = interval > 1 ? p.delta_t * (0.5f * (float)interval) : 0.0f;
     return T;
+}
+
+// log2 of the cells per sort tile (tuning: variant bits 4..7 override the default of 8 = 16x16 cells).
+uint32_t tile_log2(const pcl_compute* h)
+{
+    const uint32_t v = (h->variant >> 4) & 0xFu;
+    return v ? v : 8u;
 }
 
 // How often the tile order is refreshed: the caller's setting, or by default
@@ -457,7 +467,7 @@ int do_reorder(pcl_compute* h)
 {
     if (h->n == 0) return PCL_OK;
     if (int rc = reserve_reorder(h)) return rc;
-    const pcl::TileMap T = make_tile_map(h->params, effective_reorder_interval(h));
+    const pcl::TileMap T = make_tile_map(h->params, effective_reorder_interval(h), tile_log2(h));
     const pcl::StepUniforms U = uniforms_of(h);
     if (int rc = reorder_count(h, U, T)) return rc;
     pcl::ReorderArgs a;
@@ -529,7 +539,7 @@ int do_step(pcl_compute* h)
         const int interval = effective_reorder_interval(h);
         const bool sort_now = interval > 0 && (!h->sorted || h->steps_since_sort >= (uint64_t)interval);
         // A pending histogram fixes the key function (delta_t, hence the lookahead, may change per frame).
-        const pcl::TileMap T = (sort_now && h->hist_valid) ? h->hist_tiles : make_tile_map(h->params, interval);
+        const pcl::TileMap T = (sort_now && h->hist_valid) ? h->hist_tiles : make_tile_map(h->params, interval, tile_log2(h));
         if (sort_now) {
             // Update and scatter into tile order in one pass.
             if (int rc = reserve_reorder(h)) return rc;

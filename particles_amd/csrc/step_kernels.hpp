@@ -265,54 +265,38 @@ struct TileMap {
     uint32_t n_bins;
     uint32_t max_ix[3];      // dim - 1 per axis (an index equal to dim is clamped)
     float lookahead;         // seconds: the key is the tile of pos + vel * lookahead
+    float inv_cell[3];       // cells per unit length per axis (0 when the range is degenerate)
 };
 
 // Sort key of a particle: the field tile of where it will be `lookahead`
 // seconds from now (half a refresh interval), so that the order is at its
 // best in the middle of the interval instead of at its start.  Only a
-// locality heuristic: any key gives the same per-particle results.
+// locality heuristic — any key gives the same per-particle results — so it
+// uses a reciprocal multiply (inv_cell = dim / (2 slh)) instead of the exact
+// division of the field fetch; what matters is that every kernel computes it
+// with this one function.
 __device__ __forceinline__ uint32_t tile_key(const StepUniforms& U, const TileMap& T,
                                              float x, float y, float z, float vx, float vy, float vz)
 {
-    uint32_t ix = 0u, iy = 0u, iz = 0u;
-    if (!U.degenerate) {
-        ix = (uint32_t)map_range_axis(U, x + vx * T.lookahead, U.span_b[0]);
-        iy = (uint32_t)map_range_axis(U, y + vy * T.lookahead, U.span_b[1]);
-        iz = (uint32_t)map_range_axis(U, z + vz * T.lookahead, U.span_b[2]);
-    }
+    const float px = fminf(fmaxf(x + vx * T.lookahead, U.neg_slh), U.slh);
+    const float py = fminf(fmaxf(y + vy * T.lookahead, U.neg_slh), U.slh);
+    const float pz = fminf(fmaxf(z + vz * T.lookahead, U.neg_slh), U.slh);
+    uint32_t ix = (uint32_t)((px - U.neg_slh) * T.inv_cell[0]);
+    uint32_t iy = (uint32_t)((py - U.neg_slh) * T.inv_cell[1]);
+    uint32_t iz = (uint32_t)((pz - U.neg_slh) * T.inv_cell[2]);
     ix = ix < T.max_ix[0] ? ix : T.max_ix[0];
     iy = iy < T.max_ix[1] ? iy : T.max_ix[1];
     iz = iz < T.max_ix[2] ? iz : T.max_ix[2];
     return ((ix >> T.sx) * T.nty + (iy >> T.sy)) * T.ntz + (iz >> T.sz);
 }
 
-// counters[key] += 1 for every active lane, returning each lane's rank within
-// its counter.  Particles kept in tile order make most lanes of a wave share
-// one key, and 64 same-address LDS atomics serialise; so lanes with equal keys
-// are combined into one add by their first lane (up to 4 distinct keys per
-// call, then plain per-lane atomics for what is left).
+// counters[key] += 1, returning this particle's rank within its counter.
+// Plain LDS atomics: combining equal keys across the wave first was measured
+// and bought nothing (the LDS serves same-address atomics quickly) while
+// costing ~100 VALU instructions per call.
 __device__ __forceinline__ uint32_t lds_rank_add(uint32_t* counters, uint32_t key, bool active)
 {
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    uint32_t rank = 0u;
-    unsigned long long todo = __ballot(active);
-    for (int iter = 0; todo != 0ull; ++iter) {
-        if (iter == 4) {
-            if ((todo >> lane) & 1ull) rank = atomicAdd(&counters[key], 1u);
-            break;
-        }
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t lk = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
-        const bool mine = ((todo >> lane) & 1ull) && key == lk;
-        const unsigned long long same = __ballot(mine);
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
-        uint32_t base = 0u;
-        if (lane == leader) base = atomicAdd(&counters[lk], (uint32_t)__popcll(same));
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-        if (mine) rank = base + below;
-        todo &= ~same;
-    }
-    return rank;
+    return active ? atomicAdd(&counters[key], 1u) : 0u;
 }
 
 struct StreamArgs {
