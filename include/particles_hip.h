@@ -237,8 +237,8 @@ int pcl_timer_stop(pcl_compute* h, float* elapsed_ms);
  * sits in, refreshed every `interval` steps by one counting-sort pass, so that
  * the per-particle field fetch stays cache-resident for fields larger than an
  * XCD's L2.  Per-particle results are unchanged bit for bit and every read
- * returns caller order.  interval: -1 automatic (default: on for fields above
- * 2 MiB and at least 2^22 particles), 0 never, k > 0 every k steps. */
+ * returns caller order.  interval: -1 automatic (default: every 12 steps for
+ * fields above 64 KiB and at least 2^20 particles), 0 never, k > 0 every k steps. */
 int pcl_set_reorder_interval(pcl_compute* h, int interval);
 
 /* Sort by field tile now (also the first step does when reordering is on). */
