@@ -88,13 +88,21 @@ def cpu_baseline(sp, field, seed, pos_extent, budget_s=12.0):
         el = time.perf_counter() - t0
         if el >= budget_s or steps >= 256:
             break
+    # single-thread point on a quarter of the sample
+    q = p[: n // 4].copy()
+    t1 = time.perf_counter()
+    for _ in range(2):
+        q = O.step(sp, q, field, mode=O.MODE_SKIP_INERT, threads=1)
+    single = (n // 4) * 2 / (time.perf_counter() - t1)
     return {
         "value": n * steps / el,
         "unit": "particle-steps/s",
         "cores": threads,
         "kind": "port",
         "sample": f"{steps} steps of {n} particles (same field, params and distributions), "
-                  f"C oracle -O3, {threads} OpenMP threads, {el:.1f} s",
+                  f"C oracle -O3, {threads} OpenMP threads, {el:.1f} s; "
+                  f"one thread: {single:.3g} particle-steps/s; host has {os.cpu_count()} logical CPUs",
+        "single_thread_value": single,
     }
 
 
