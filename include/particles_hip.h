@@ -247,6 +247,23 @@ int pcl_reorder_now(pcl_compute* h);
 /* Number of sort passes run so far. */
 uint64_t pcl_reorder_count(const pcl_compute* h);
 
+/* What one pcl_step launched (pcl_step_timing_read). */
+enum {
+    PCL_STEP_NONE           = 0,
+    PCL_STEP_STREAM         = 1, /* step_stream_kernel                                      */
+    PCL_STEP_PAIRS          = 2, /* step_pairs_kernel                                       */
+    PCL_STEP_STREAM_COUNT   = 3, /* step_stream_kernel that also histograms the field tiles */
+    PCL_STEP_STREAM_SCATTER = 4  /* step_scatter_kernel: update + refresh of the tile order */
+};
+
+/* Per-launch timing: between begin and read every pcl_step is bracketed by a
+ * HIP event pair on the handle's stream (no synchronisation until the read).
+ * read waits for the last step, fills elapsed_ms[i] / kinds[i] (PCL_STEP_*) for
+ * the recorded steps and stops the recording. */
+int pcl_step_timing_begin(pcl_compute* h, size_t max_steps);
+int pcl_step_timing_read(pcl_compute* h, float* elapsed_ms, int32_t* kinds,
+                         size_t capacity, size_t* count);
+
 /* Geometry of the streaming kernel's launch (for reports). */
 int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks,
                         uint32_t* block_threads, uint32_t* particles_per_lane);

@@ -16,6 +16,7 @@ PCL_ERR_NO_DEVICE = -3
 PCL_ERR_OUT_OF_RANGE = -4
 
 KERNEL_NONE, KERNEL_STREAM, KERNEL_PAIRS = 0, 1, 2
+STEP_NONE, STEP_STREAM, STEP_PAIRS, STEP_STREAM_COUNT, STEP_STREAM_SCATTER = 0, 1, 2, 3, 4
 
 
 class PclError(RuntimeError):
@@ -73,6 +74,8 @@ SIGNATURES = {
     "pcl_synchronize": (_i, [_vp]),
     "pcl_timer_start": (_i, [_vp]),
     "pcl_timer_stop": (_i, [_vp, C.POINTER(_f)]),
+    "pcl_step_timing_begin": (_i, [_vp, _sz]),
+    "pcl_step_timing_read": (_i, [_vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "pcl_launch_geometry": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "pcl_set_reorder_interval": (_i, [_vp, _i]),
     "pcl_reorder_now": (_i, [_vp]),

@@ -207,6 +207,21 @@ class Compute:
         _lib.check(self._lib.pcl_timer_stop(self._h, C.byref(ms)))
         return float(ms.value)
 
+    def step_timing_begin(self, max_steps):
+        """Bracket each of the next ``max_steps`` steps with a HIP event pair."""
+        _lib.check(self._lib.pcl_step_timing_begin(self._h, int(max_steps)))
+        self._timing_cap = int(max_steps)
+
+    def step_timing_read(self):
+        """(elapsed_ms float32[n], kinds int32[n]) of the recorded steps."""
+        cap = getattr(self, "_timing_cap", 0)
+        ms = np.zeros(cap, dtype=np.float32)
+        kinds = np.zeros(cap, dtype=np.int32)
+        n = C.c_size_t()
+        _lib.check(self._lib.pcl_step_timing_read(self._h, _ptr(ms) if cap else None, _ptr(kinds) if cap else None,
+                                                  cap, C.byref(n)))
+        return ms[: n.value], kinds[: n.value]
+
     def launch_geometry(self):
         g, b, p = C.c_uint32(), C.c_uint32(), C.c_uint32()
         _lib.check(self._lib.pcl_launch_geometry(self._h, C.byref(g), C.byref(b), C.byref(p)))

@@ -121,6 +121,12 @@ struct pcl_compute {
 
     uint32_t grid_cap = 0;  // 0: default
     uint32_t variant = 0;
+
+    // per-step launch timing (pcl_step_timing_*): one event pair per step
+    std::vector<hipEvent_t> timing_events;
+    std::vector<int> timing_kinds;
+    size_t timing_used = 0;
+    bool timing_on = false;
 };
 
 namespace {
@@ -519,12 +525,13 @@ int caller_order_map(pcl_compute* h, const uint32_t** out)
     return PCL_OK;
 }
 
-int do_step(pcl_compute* h)
+int do_step_impl(pcl_compute* h, int* kind)
 {
     if (int rc = bind(h)) return rc;
     const bool inert = pair_term_inert(h->params);
     const bool use_pairs = h->force_pairs || !inert;
     h->last_kernel = use_pairs ? PCL_KERNEL_PAIRS : PCL_KERNEL_STREAM;
+    *kind = use_pairs ? PCL_STEP_PAIRS : PCL_STEP_STREAM;
     if (h->n == 0) {
         h->cur ^= 1;
         h->steps += 1;
@@ -563,6 +570,7 @@ int do_step(pcl_compute* h)
             reorder_commit(h);
             h->steps_since_sort = 0;   // incremented below: the new order is one step old
             flipped = true;
+            *kind = PCL_STEP_STREAM_SCATTER;
         } else {
             // The step before a sort also histograms its output positions.
             const bool count = interval > 1 && h->sorted && h->steps_since_sort + 1 >= (uint64_t)interval &&
@@ -594,6 +602,7 @@ int do_step(pcl_compute* h)
             if (rc) return rc;
             h->hist_valid = count;
             if (count) h->hist_tiles = T;
+            if (count) *kind = PCL_STEP_STREAM_COUNT;
         }
     } else {
         if (int rc = restore_caller_order(h)) return rc;   // the pair sums run in caller order
@@ -650,6 +659,24 @@ int do_step(pcl_compute* h)
         h->diag_current = false;
     }
     return PCL_OK;
+}
+
+// One step; with step timing on, bracketed by an event pair on the stream.
+int do_step(pcl_compute* h)
+{
+    int kind = PCL_STEP_NONE;
+    const bool timed = h && h->timing_on && h->timing_used < h->timing_kinds.size();
+    if (timed) {
+        if (int rc = bind(h)) return rc;
+        PCL_HIP_TRY(hipEventRecord(h->timing_events[2 * h->timing_used], h->stream));
+    }
+    const int rc = do_step_impl(h, &kind);
+    if (timed) {
+        PCL_HIP_TRY(hipEventRecord(h->timing_events[2 * h->timing_used + 1], h->stream));
+        h->timing_kinds[h->timing_used] = rc == PCL_OK ? kind : PCL_STEP_NONE;
+        h->timing_used += 1;
+    }
+    return rc;
 }
 
 // Reduce diagnostics of state[cur] into h->d_diag unless already current.
@@ -721,6 +748,7 @@ int pcl_destroy(pcl_compute* h)
     if (h->d_partials) (void)hipFree(h->d_partials);
     if (h->d_diag) (void)hipFree(h->d_diag);
     if (h->d_hist) (void)hipFree(h->d_hist);
+    for (hipEvent_t e : h->timing_events) (void)hipEventDestroy(e);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1125,6 +1153,36 @@ int pcl_timer_stop(pcl_compute* h, float* elapsed_ms)
     PCL_HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
     PCL_HIP_TRY(hipEventSynchronize(h->ev_stop));
     PCL_HIP_TRY(hipEventElapsedTime(elapsed_ms, h->ev_start, h->ev_stop));
+    return PCL_OK;
+}
+
+int pcl_step_timing_begin(pcl_compute* h, size_t max_steps)
+{
+    if (int rc = bind(h)) return rc;
+    while (h->timing_events.size() < 2 * max_steps) {
+        hipEvent_t e = nullptr;
+        PCL_HIP_TRY(hipEventCreate(&e));
+        h->timing_events.push_back(e);
+    }
+    h->timing_kinds.assign(max_steps, PCL_STEP_NONE);
+    h->timing_used = 0;
+    h->timing_on = max_steps > 0;
+    return PCL_OK;
+}
+
+int pcl_step_timing_read(pcl_compute* h, float* elapsed_ms, int32_t* kinds, size_t capacity, size_t* count)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_REQUIRE(count != nullptr, "pcl_step_timing_read: count is null");
+    h->timing_on = false;
+    const size_t n = std::min(capacity, h->timing_used);
+    PCL_REQUIRE(n == 0 || (elapsed_ms != nullptr && kinds != nullptr), "pcl_step_timing_read: null output");
+    if (h->timing_used) PCL_HIP_TRY(hipEventSynchronize(h->timing_events[2 * h->timing_used - 1]));
+    for (size_t i = 0; i < n; ++i) {
+        PCL_HIP_TRY(hipEventElapsedTime(&elapsed_ms[i], h->timing_events[2 * i], h->timing_events[2 * i + 1]));
+        kinds[i] = h->timing_kinds[i];
+    }
+    *count = n;
     return PCL_OK;
 }
 

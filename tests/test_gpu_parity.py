@@ -360,3 +360,23 @@ def test_changing_dt_between_counting_and_scatter_steps(oracle):
             cur = oracle.step(sp, cur, g, mode=oracle.MODE_SKIP_INERT)
         assert c.reorder_count >= 3
         assert_particles_bit_equal(c.read_particles(), cur, "per-frame dt")
+
+
+def test_step_timing_reports_each_launch_and_its_kind():
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = (64, 64, 1)
+    g = scene_swirl_field(64, 64, 1, 10.0, seed=2)
+    with pa.Compute.new(pa.empty_particles(0), g) as c:
+        c.update_sim_params(sp)
+        c.generate_particles(1 << 16, seed=1, pos_extent=20.0)
+        c.set_reorder_interval(4)
+        c.step_timing_begin(9)
+        for _ in range(9):
+            c.compute()
+        ms, kinds = c.step_timing_read()
+        assert ms.shape == (9,) and np.all(ms > 0)
+        # first step sorts (scatter), then every 4th; the step before a sort also counts
+        assert kinds.tolist() == [4, 1, 1, 3, 4, 1, 1, 3, 4]
+        c.compute()
+        assert c.step_timing_read()[0].size == 9             # recording stopped: nothing new was appended
