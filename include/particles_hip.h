@@ -180,6 +180,17 @@ int pcl_step_dt(pcl_compute* h, float delta_t);
  * zero; for equivalence tests.  0 = automatic choice (default). */
 int pcl_force_pair_kernel(pcl_compute* h, int enable);
 
+/* How the pair term (src/compute.wgsl:115-144) is evaluated when it is not
+ * provably zero.  PCL_PAIRS_ALL: the shader's sweep over all N particles in
+ * index order (bit-exact summation order).  PCL_PAIRS_BINNED: particles are
+ * sorted into cells of edge >= cut_off_distance and only the 27 surrounding
+ * cells are swept: same skip tests and force expression, sums equal up to
+ * fp32 summation order, O(N k) instead of O(N^2).  PCL_PAIRS_AUTO (default):
+ * binned from 2^15 particles on when the cut-off allows at least 3 cells per
+ * axis, the exact sweep otherwise. */
+enum { PCL_PAIRS_AUTO = 0, PCL_PAIRS_ALL = 1, PCL_PAIRS_BINNED = 2 };
+int pcl_set_pair_mode(pcl_compute* h, int mode);
+
 /* PCL_KERNEL_* of the most recent step. */
 int pcl_last_step_kernel(const pcl_compute* h);
 
@@ -253,7 +264,8 @@ enum {
     PCL_STEP_STREAM         = 1, /* step_stream_kernel                                      */
     PCL_STEP_PAIRS          = 2, /* step_pairs_kernel                                       */
     PCL_STEP_STREAM_COUNT   = 3, /* step_stream_kernel that also histograms the field tiles */
-    PCL_STEP_STREAM_SCATTER = 4  /* step_scatter_kernel: update + refresh of the tile order */
+    PCL_STEP_STREAM_SCATTER = 4, /* step_scatter_kernel: update + refresh of the tile order */
+    PCL_STEP_PAIRS_BINNED   = 5  /* sort by cut-off cell + step_pairs_binned_kernel            */
 };
 
 /* Per-launch timing: between begin and read every pcl_step is bracketed by a

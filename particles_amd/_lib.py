@@ -16,7 +16,8 @@ PCL_ERR_NO_DEVICE = -3
 PCL_ERR_OUT_OF_RANGE = -4
 
 KERNEL_NONE, KERNEL_STREAM, KERNEL_PAIRS = 0, 1, 2
-STEP_NONE, STEP_STREAM, STEP_PAIRS, STEP_STREAM_COUNT, STEP_STREAM_SCATTER = 0, 1, 2, 3, 4
+STEP_NONE, STEP_STREAM, STEP_PAIRS, STEP_STREAM_COUNT, STEP_STREAM_SCATTER, STEP_PAIRS_BINNED = 0, 1, 2, 3, 4, 5
+PAIRS_AUTO, PAIRS_ALL, PAIRS_BINNED = 0, 1, 2
 
 
 class PclError(RuntimeError):
@@ -60,6 +61,7 @@ SIGNATURES = {
     "pcl_step": (_i, [_vp]),
     "pcl_step_dt": (_i, [_vp, _f]),
     "pcl_force_pair_kernel": (_i, [_vp, _i]),
+    "pcl_set_pair_mode": (_i, [_vp, _i]),
     "pcl_last_step_kernel": (_i, [_vp]),
     "pcl_enable_step_diagnostics": (_i, [_vp, _i]),
     "pcl_num_particles": (_sz, [_vp]),

@@ -182,6 +182,10 @@ class Compute:
         _lib.check(self._lib.pcl_debug_cell_indices(self._h, _ptr(out), int(first), int(count)))
         return out
 
+    def set_pair_mode(self, mode):
+        """0 automatic, 1 all-pairs sweep in index order (bit-exact), 2 cell-binned."""
+        _lib.check(self._lib.pcl_set_pair_mode(self._h, int(mode)))
+
     def force_pair_kernel(self, enable=True):
         _lib.check(self._lib.pcl_force_pair_kernel(self._h, int(bool(enable))))
 

@@ -66,6 +66,7 @@ constexpr uint32_t kLdsFieldMaxBytes = 64u * 1024u;  // fields up to this size a
 constexpr int kAutoReorderInterval = 12;               // steps between refreshes of the tile order
 constexpr size_t kAutoReorderMinFieldBytes = 64u * 1024u;        // smaller fields are staged in LDS instead
 constexpr size_t kAutoReorderMinParticles = size_t(1) << 20;
+constexpr size_t kPairBinnedMinParticles = size_t(1) << 15;  // automatic switch to the cell-binned pair kernel
 constexpr size_t kPairSmallSet = size_t(1) << 18;     // up to here the pair kernel runs one wave per block
 constexpr size_t kArrayStagger = 4096;                // see reserve_particles
 constexpr uint32_t kFoldBlocks = 64;                 // first-level blocks of the diagnostics fold
@@ -111,6 +112,7 @@ struct pcl_compute {
     bool params_dirty = true;
 
     bool force_pairs = false;
+    int pair_mode = 0;                 // PCL_PAIRS_AUTO / _ALL / _BINNED
     bool step_diag = false;
     bool diag_current = false;  // d_diag describes state[cur]
     int last_kernel = PCL_KERNEL_NONE;
@@ -525,6 +527,41 @@ int caller_order_map(pcl_compute* h, const uint32_t** out)
     return PCL_OK;
 }
 
+// Uniform grid of at most 20^3 cells whose edge is at least 1.0001 x the
+// cut-off (the margin absorbs the rounding of the reciprocal-multiply key), as a
+// TileMap with unit tiles: the sort key is (cx * n + cy) * n + cz.
+pcl::TileMap make_pair_cell_map(const pcl_sim_params& p)
+{
+    const double side = 2.0 * (double)p.bounding_volume_radius;
+    const double edge = (double)p.cut_off_distance * 1.0001;
+    uint32_t n = 1;
+    if (side > 0.0 && edge > 0.0 && std::isfinite(side) && std::isfinite(edge))
+        n = (uint32_t)std::min(20.0, std::max(1.0, std::floor(side / edge)));
+    pcl::TileMap C;
+    C.sx = C.sy = C.sz = 0;
+    C.nty = C.ntz = n;
+    C.n_bins = n * n * n;
+    for (int a = 0; a < 3; ++a) {
+        C.max_ix[a] = n - 1u;
+        C.inv_cell[a] = (side > 0.0 && std::isfinite(side)) ? (float)((double)n / side) : 0.0f;
+    }
+    C.lookahead = 0.0f;
+    return C;
+}
+
+bool use_binned_pairs(const pcl_compute* h)
+{
+    if (h->pair_mode == PCL_PAIRS_ALL) return false;
+    if (h->n >= 0xFFFFFFFFull || h->n < 2) return false;
+    const pcl_sim_params& p = h->params;
+    const bool usable = p.cut_off_distance > 0.0f && std::isfinite(p.cut_off_distance) &&
+                        p.bounding_volume_radius > 0.0f && std::isfinite(p.bounding_volume_radius);
+    if (!usable) return false;
+    if (h->pair_mode == PCL_PAIRS_BINNED) return true;
+    // automatic: only where the all-pairs sweep is the slower one
+    return h->n >= kPairBinnedMinParticles && make_pair_cell_map(p).n_bins >= 27;
+}
+
 int do_step_impl(pcl_compute* h, int* kind)
 {
     if (int rc = bind(h)) return rc;
@@ -604,6 +641,51 @@ int do_step_impl(pcl_compute* h, int* kind)
             if (count) h->hist_tiles = T;
             if (count) *kind = PCL_STEP_STREAM_COUNT;
         }
+    } else if (use_binned_pairs(h)) {
+        // Cell-binned pair term: sort by cut-off cell, then sweep the 27 neighbour cells.
+        h->hist_valid = false;
+        if (h->params_dirty) {
+            PCL_HIP_TRY(hipMemcpyAsync(h->d_params, &h->params, sizeof(pcl_sim_params),
+                                       hipMemcpyHostToDevice, h->stream));
+            PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+            h->params_dirty = false;
+        }
+        if (int rc = reserve_reorder(h)) return rc;
+        const pcl::TileMap C = make_pair_cell_map(h->params);
+        if (int rc = reorder_count(h, U, C)) return rc;
+        pcl::ReorderArgs ra;
+        uint32_t sgrid = 0;
+        if (int rc = reorder_prepare(h, C, &ra, &sgrid)) return rc;
+        hipLaunchKernelGGL(pcl::reorder_scatter_kernel, dim3(sgrid), dim3(pcl::kStreamThreads),
+                           pcl::scatter_lds_bytes(C.n_bins), h->stream, ra, U, C);
+        PCL_HIP_TRY(hipGetLastError());
+        reorder_commit(h);
+        h->steps_since_sort = 0;
+        const size_t blocks = (h->n + pcl::kBlockThreads - 1) / pcl::kBlockThreads;
+        PCL_REQUIRE(blocks <= 0x7FFFFFFFu, "too many particles for the pair kernel");
+        grid = (uint32_t)blocks;
+        if (h->step_diag)
+            if (int rc = reserve_partials(h, grid)) return rc;
+        const int src = h->cur, dst = h->cur ^ 1;
+        pcl::PairArgs a;
+        for (int k = 0; k < 6; ++k) { a.src[k] = h->state[src][k]; a.dst[k] = h->state[dst][k]; }
+        a.ty = cur_ty(h);
+        a.field = h->field;
+        a.params = reinterpret_cast<const pcl::ParamsBlock*>(h->d_params);
+        a.n = h->n;
+        a.partials = h->d_partials;
+        a.s_near = smallest_square_with([](float len) { return !(len < 0.001f); });
+        const float cut = h->params.cut_off_distance;
+        a.s_far = smallest_square_with([cut](float len) { return len > cut; });
+        const uint32_t* bin_end = h->d_hist + pcl::kMaxReorderBins;   // the cursors after the scatter
+        if (h->step_diag)
+            hipLaunchKernelGGL((pcl::step_pairs_binned_kernel<true>), dim3(grid), dim3(pcl::kBlockThreads), 0,
+                               h->stream, a, U, C, bin_end);
+        else
+            hipLaunchKernelGGL((pcl::step_pairs_binned_kernel<false>), dim3(grid), dim3(pcl::kBlockThreads), 0,
+                               h->stream, a, U, C, bin_end);
+        PCL_HIP_TRY(hipGetLastError());
+        *kind = PCL_STEP_PAIRS_BINNED;
     } else {
         if (int rc = restore_caller_order(h)) return rc;   // the pair sums run in caller order
         h->hist_valid = false;
@@ -987,6 +1069,15 @@ int pcl_force_pair_kernel(pcl_compute* h, int enable)
 {
     if (!h) return fail(PCL_ERR_INVALID, "null handle");
     h->force_pairs = enable != 0;
+    return PCL_OK;
+}
+
+int pcl_set_pair_mode(pcl_compute* h, int mode)
+{
+    if (!h) return fail(PCL_ERR_INVALID, "null handle");
+    PCL_REQUIRE(mode == PCL_PAIRS_AUTO || mode == PCL_PAIRS_ALL || mode == PCL_PAIRS_BINNED,
+                "pcl_set_pair_mode: unknown mode");
+    h->pair_mode = mode;
     return PCL_OK;
 }
 

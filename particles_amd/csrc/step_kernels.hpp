@@ -539,6 +539,83 @@ __global__ __launch_bounds__(PB) void step_pairs_kernel(PairArgs a, StepUniforms
     if (DIAG) block_reduce_store<PB>(acc, a.partials + blockIdx.x);
 }
 
+// Cell-binned pair term.  With the particles sorted by a uniform grid of cells
+// whose edge is at least cut_off_distance (key = tile_key with the cell map C,
+// lookahead 0), every partner of particle i within the cut-off lies in the 27
+// cells around i's cell, and the three cells of one (x, y) column are adjacent
+// bins, i.e. one contiguous slot range [bin_end[b0-1], bin_end[b1]).  The
+// skip tests and the force expression are those of wgsl:120-139; what changes
+// against step_pairs_kernel is the ORDER in which a particle's terms are added
+// (cell order instead of j = 0..N-1), so results agree with the shader up to
+// fp32 summation order instead of bit for bit.  Work per particle drops from N
+// to the population of 27 cells.
+template <bool DIAG>
+__global__ __launch_bounds__(kBlockThreads) void step_pairs_binned_kernel(
+    PairArgs a, StepUniforms U, TileMap C, const uint32_t* __restrict__ bin_end)
+{
+    __shared__ float polys[25 * 8];
+    for (int k = threadIdx.x; k < 25 * 8; k += kBlockThreads)
+        polys[k] = a.params->polys[k / 8][k % 8];
+    __syncthreads();
+    const float exponent = a.params->distance_exponent;
+
+    const unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x;
+    const bool live = i < a.n;
+    DiagAcc acc;
+    if (DIAG) acc.init();
+    if (live) {
+        float x = a.src[0][i], y = a.src[1][i], z = a.src[2][i];
+        float vx = a.src[3][i], vy = a.src[4][i], vz = a.src[5][i];
+        const uint32_t my_ty = a.ty[i];
+        const float* my_polys = &polys[my_ty * 5u * 8u];
+        // this particle's cell, exactly as the sort keyed it (shifts are 0 in a cell map)
+        const float px = fminf(fmaxf(x, U.neg_slh), U.slh);
+        const float py = fminf(fmaxf(y, U.neg_slh), U.slh);
+        const float pz = fminf(fmaxf(z, U.neg_slh), U.slh);
+        uint32_t cx = (uint32_t)((px - U.neg_slh) * C.inv_cell[0]);
+        uint32_t cy = (uint32_t)((py - U.neg_slh) * C.inv_cell[1]);
+        uint32_t cz = (uint32_t)((pz - U.neg_slh) * C.inv_cell[2]);
+        cx = cx < C.max_ix[0] ? cx : C.max_ix[0];
+        cy = cy < C.max_ix[1] ? cy : C.max_ix[1];
+        cz = cz < C.max_ix[2] ? cz : C.max_ix[2];
+        const uint32_t z0 = cz > 0u ? cz - 1u : 0u;
+        const uint32_t z1 = cz < C.max_ix[2] ? cz + 1u : cz;
+        float ax = 0.0f, ay = 0.0f, az = 0.0f;
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int X = (int)cx + dx;
+            if (X < 0 || X > (int)C.max_ix[0]) continue;
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int Y = (int)cy + dy;
+                if (Y < 0 || Y > (int)C.max_ix[1]) continue;
+                const uint32_t b0 = ((uint32_t)X * C.nty + (uint32_t)Y) * C.ntz + z0;
+                const uint32_t b1 = b0 + (z1 - z0);
+                const uint32_t j0 = b0 ? bin_end[b0 - 1u] : 0u;
+                const uint32_t j1 = bin_end[b1];
+                for (uint32_t j = j0; j < j1; ++j) {
+                    const float ddx = a.src[0][j] - x, ddy = a.src[1][j] - y, ddz = a.src[2][j] - z;
+                    const float s = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                    if (j == (uint32_t)i || s < a.s_near || s >= a.s_far) continue;   // wgsl:120-131
+                    const float len = sqrtf(s);
+                    const float df = exponent == 0.0f ? 1.0f : powf(len, exponent);
+                    const uint32_t oty = a.ty[j];
+                    const float m2 = mass_of(U, oty);
+                    const float pv = eval_poly7(len, &my_polys[oty * 8u]);
+                    ax = ax + ((__fdiv_rn(ddx, len) * pv) * m2) * df;    // wgsl:139
+                    ay = ay + ((__fdiv_rn(ddy, len) * pv) * m2) * df;
+                    az = az + ((__fdiv_rn(ddz, len) * pv) * m2) * df;
+                }
+            }
+        }
+        const float m = mass_of(U, my_ty);
+        const f32x4 f = a.field[cell_index(U, x, y, z)];
+        integrate(U, f.x, f.y, f.z, m, ax, ay, az, x, y, z, vx, vy, vz);
+        a.dst[0][i] = x; a.dst[1][i] = y; a.dst[2][i] = z;
+        a.dst[3][i] = vx; a.dst[4][i] = vy; a.dst[5][i] = vz;
+        if (DIAG) acc.add(m, x, y, z, vx, vy, vz);
+    }
+    if (DIAG) block_reduce_store(acc, a.partials + blockIdx.x);
+}
+
 // ------------------------------------------------- standalone diagnostics K3
 
 __global__ __launch_bounds__(kBlockThreads) void diag_reduce_kernel(

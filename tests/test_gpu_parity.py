@@ -380,3 +380,85 @@ def test_step_timing_reports_each_launch_and_its_kind():
         assert kinds.tolist() == [4, 1, 1, 3, 4, 1, 1, 3, 4]
         c.compute()
         assert c.step_timing_read()[0].size == 9             # recording stopped: nothing new was appended
+
+
+# ---- cell-binned pair term: same terms, different summation order
+
+def _close(got, want, two_r, rtol=1e-5, atol=1e-6):
+    """|a-b| <= rtol*max(|a|,|b|) + atol, positions modulo the wrap.  A different
+    summation order perturbs each acceleration by ~eps times the size of its
+    TERMS (which cancel), so callers pass an atol scaled to the accelerations."""
+    for f in ("pos", "vel"):
+        a, b = got[f][:, :3].astype(np.float64), want[f][:, :3].astype(np.float64)
+        d = np.abs(a - b)
+        if f == "pos":
+            d = np.minimum(d, np.abs(two_r - d))       # modulo the wrap
+        bad = d > rtol * np.maximum(np.abs(a), np.abs(b)) + atol
+        assert not bad.any(), f"{f}: {bad.sum()} components out of tolerance, worst {d.max()}"
+
+
+@pytest.mark.parametrize("n,cutoff,extent,exponent", [
+    (3000, 1.5, 20.0, 0.0), (3001, 0.7, 6.0, 0.0), (8192, 2.5, 20.0, -1.0), (257, 30.0, 20.0, 0.0), (5000, 1.0, 40.0, 0.5)])
+def test_binned_pair_kernel_matches_oracle(oracle, n, cutoff, extent, exponent):
+    sp = pair_params(exponent)
+    sp.cut_off_distance = cutoff
+    g = sp.new_force_grid_centered().get_force_vectors()
+    p = oracle.synth_particles(n, seed=n, pos_extent=extent, vel_extent=10.0)   # extent 40: particles outside the box
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        c.set_pair_mode(2)
+        c.compute()
+        got = c.read_particles()
+        assert c.last_step_kernel == pa.KERNEL_PAIRS
+    want = oracle.run(sp, p, g, 1)
+    # scale of the velocity changes in this scene (accelerations * dt)
+    dv = np.abs(want["vel"][:, :3] - p["vel"][:, :3] * np.float32(np.exp(-float(sp.delta_t)))).max()
+    _close(got, want, 2.0 * sp.bounding_volume_radius, atol=1e-6 + 1e-5 * float(dv))
+    # the fetch index does not depend on the summation order: exact
+    assert np.array_equal(got["ty"], want["ty"])
+
+
+def test_binned_and_exact_pair_kernels_agree_over_steps(oracle):
+    sp = pair_params(0.0)
+    sp.polys[:] *= np.float32(0.05)          # gentle forces: keep the 3-step horizon short of chaos
+    g = sp.new_force_grid_centered().get_force_vectors()
+    p = oracle.synth_particles(20000, seed=77, pos_extent=20.0, vel_extent=2.0)
+    out = []
+    for mode in (1, 2):
+        with pa.Compute.new(p, g) as c:
+            c.update_sim_params(sp)
+            c.set_pair_mode(mode)
+            for _ in range(3):
+                c.compute()
+            out.append(c.read_particles())
+            d = c.diagnostics()
+            assert d["count"] == 20000
+    _close(out[1], out[0], 2.0 * sp.bounding_volume_radius, rtol=1e-4, atol=1e-5)
+    want = oracle.run(sp, p, g, 3)
+    assert_particles_bit_equal(out[0], want, "exact sweep, 3 steps")
+
+
+def test_binned_pairs_then_stream_then_exact(oracle):
+    """Order bookkeeping across kernel families: binned pairs (cell order) ->
+    streaming (field-tile order) -> exact pairs (caller order)."""
+    sp = pair_params(0.0)
+    g = sp.new_force_grid_centered().get_force_vectors()
+    p = oracle.synth_particles(6000, seed=5, pos_extent=20.0, vel_extent=5.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        c.set_pair_mode(2)
+        c.compute()
+        mid1 = c.read_particles()
+        _close(mid1, oracle.run(sp, p, g, 1), 20.0)
+        sp0 = pa.SimParams()
+        sp0.delta_t = DT
+        c.update_sim_params(sp0)                 # zero force curves: streaming kernel
+        c.set_reorder_interval(1)
+        c.compute()
+        assert c.last_step_kernel == pa.KERNEL_STREAM
+        mid2 = c.read_particles()
+        assert_particles_bit_equal(mid2, oracle.run(sp0, mid1, g, 1, mode=oracle.MODE_SKIP_INERT), "stream after binned")
+        c.update_sim_params(sp)
+        c.set_pair_mode(1)
+        c.compute()
+        assert_particles_bit_equal(c.read_particles(), oracle.run(sp, mid2, g, 1), "exact pairs after stream")

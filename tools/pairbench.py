@@ -15,23 +15,29 @@ def main():
     sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
     sp.polys[:] = np.random.default_rng(1).uniform(-1, 1, size=(25, 8)).astype(np.float32)
     g = sp.new_force_grid_centered().get_force_vectors()
-    for exponent in (0.0, -1.0):
+    for mode in (1, 2):
+      for exponent in (0.0,):
         sp.distance_exponent = exponent
         for extent in (2.0, 20.0):
-            for n in (1000, 4096, 16384, 50000, 131072):
+            for n in (1000, 16384, 50000, 131072, 1 << 20, 1 << 24):
+                if mode == 1 and n > 131072:
+                    continue
+                if extent == 2.0 and n > (1 << 20):
+                    continue
                 with pa.Compute.new(pa.empty_particles(0), g) as c:
                     c.update_sim_params(sp)
+                    c.set_pair_mode(mode)
                     c.generate_particles(n, 7, 0, extent, 10.0)
                     for _ in range(2):
                         c.compute()
                     c.synchronize()
-                    steps = 10 if n <= 50000 else 3
+                    steps = 10 if n <= 50000 else 2
                     c.timer_start()
                     for _ in range(steps):
                         c.compute()
                     ms = c.timer_stop() / steps
                     assert c.last_step_kernel == pa.KERNEL_PAIRS
-                    print(f"exponent {exponent:4.1f} extent {extent:4.1f} n {n:7d}: {ms:9.4f} ms/step  "
+                    print(f"mode {mode} exponent {exponent:4.1f} extent {extent:4.1f} n {n:7d}: {ms:9.4f} ms/step  "
                           f"{n * n / ms / 1e6:9.2f} G pair visits/s", flush=True)
 
 
