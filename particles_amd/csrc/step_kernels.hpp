@@ -464,6 +464,68 @@ struct PairArgs {
     float s_far;
 };
 
+// One term of wgsl:132-139 for a partner that passed the skip tests.
+__device__ __forceinline__ void pair_term(const f32x4 o, float x, float y, float z, float exponent,
+                                          const StepUniforms& U, const float* my_polys, float& tx, float& ty, float& tz)
+{
+    const float dx = o.x - x, dy = o.y - y, dz = o.z - z;
+    const float s = (dx * dx + dy * dy) + dz * dz;
+    const float len = sqrtf(s);
+    // pow(x, 0) is exactly 1 for every finite positive x
+    const float df = exponent == 0.0f ? 1.0f : powf(len, exponent);
+    const uint32_t oty = __float_as_uint(o.w);
+    const float m2 = mass_of(U, oty);
+    const float pv = eval_poly7(len, &my_polys[oty * 8u]);
+    tx = ((__fdiv_rn(dx, len) * pv) * m2) * df;    // wgsl:139
+    ty = ((__fdiv_rn(dy, len) * pv) * m2) * df;
+    tz = ((__fdiv_rn(dz, len) * pv) * m2) * df;
+}
+
+// One particle (this lane) against `cnt` staged candidates (x, y, z, type) in
+// LDS, in candidate order.  Two passes per 64 candidates: a cheap pass applies
+// the skip tests of wgsl:120-131 on the squared distance and records the
+// survivors in a 64-bit lane mask; a second pass evaluates wgsl:132-139 for the
+// survivors only, lowest bit first.  A wave therefore runs the expensive part
+// max-over-lanes(survivors) times instead of once per candidate whenever any
+// lane survives, and each lane still adds its terms in candidate order.  The
+// particle itself is among the candidates and drops out with s = 0 < s_near.
+__device__ __forceinline__ void sweep_candidates(const f32x4* tile, int cnt, bool live, float x, float y, float z,
+                                                 float s_near, float s_far, float exponent, const StepUniforms& U,
+                                                 const float* my_polys, float& ax, float& ay, float& az)
+{
+    for (int sb = 0; sb < cnt; sb += 64) {
+        const int m = cnt - sb < 64 ? cnt - sb : 64;   // wave-uniform
+        unsigned long long mask = 0ull;
+        if (live) {
+            if (m == 64) {
+#pragma unroll
+                for (int k = 0; k < 64; ++k) {
+                    const f32x4 o = tile[sb + k];
+                    const float dx = o.x - x, dy = o.y - y, dz = o.z - z;
+                    const float s = (dx * dx + dy * dy) + dz * dz;
+                    const bool keep = !(s < s_near) && !(s >= s_far);
+                    mask |= (unsigned long long)keep << k;
+                }
+            } else {
+                for (int k = 0; k < m; ++k) {
+                    const f32x4 o = tile[sb + k];
+                    const float dx = o.x - x, dy = o.y - y, dz = o.z - z;
+                    const float s = (dx * dx + dy * dy) + dz * dz;
+                    const bool keep = !(s < s_near) && !(s >= s_far);
+                    mask |= (unsigned long long)keep << k;
+                }
+            }
+        }
+        while (mask) {
+            const int k = __builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            float tx, ty, tz;
+            pair_term(tile[sb + k], x, y, z, exponent, U, my_polys, tx, ty, tz);
+            ax = ax + tx; ay = ay + ty; az = az + tz;
+        }
+    }
+}
+
 // All-pairs attraction (wgsl:111-144) tiled through LDS: a block owns PB
 // particles (one per lane), every tile of PB source particles is staged once
 // per block as (x, y, z, type) and swept by all lanes in index order, so each
@@ -504,26 +566,7 @@ __global__ __launch_bounds__(PB) void step_pairs_kernel(PairArgs a, StepUniforms
         __syncthreads();
         const unsigned long long rem = a.n - base;
         const int cnt = rem < (unsigned long long)PB ? (int)rem : PB;
-        // lane-local index of this particle inside the tile, or -1: wgsl:120-122
-        const int self = (live && i >= base && i < base + (unsigned long long)cnt) ? (int)(i - base) : -1;
-        if (live) {
-#pragma unroll 4
-            for (int jj = 0; jj < cnt; ++jj) {
-                const f32x4 o = tile[jj];
-                const float dx = o.x - x, dy = o.y - y, dz = o.z - z;
-                const float s = (dx * dx + dy * dy) + dz * dz;
-                if (jj == self || s < a.s_near || s >= a.s_far) continue;   // wgsl:120-131
-                const float len = sqrtf(s);
-                // pow(x, 0) is exactly 1 for every finite positive x
-                const float df = exponent == 0.0f ? 1.0f : powf(len, exponent);
-                const uint32_t oty = __float_as_uint(o.w);
-                const float m2 = mass_of(U, oty);
-                const float pv = eval_poly7(len, &my_polys[oty * 8u]);
-                ax = ax + ((__fdiv_rn(dx, len) * pv) * m2) * df;    // wgsl:139
-                ay = ay + ((__fdiv_rn(dy, len) * pv) * m2) * df;
-                az = az + ((__fdiv_rn(dz, len) * pv) * m2) * df;
-            }
-        }
+        sweep_candidates(tile, cnt, live, x, y, z, a.s_near, a.s_far, exponent, U, my_polys, ax, ay, az);
     }
 
     DiagAcc acc;

@@ -15,7 +15,8 @@ def main():
     sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
     sp.polys[:] = np.random.default_rng(1).uniform(-1, 1, size=(25, 8)).astype(np.float32)
     g = sp.new_force_grid_centered().get_force_vectors()
-    for mode in (1, 2):
+    variants = {1: (0,), 2: (0,)}
+    for mode, variant in ((m, v) for m in (1, 2) for v in variants[m]):
       for exponent in (0.0,):
         sp.distance_exponent = exponent
         for extent in (2.0, 20.0):
@@ -27,6 +28,7 @@ def main():
                 with pa.Compute.new(pa.empty_particles(0), g) as c:
                     c.update_sim_params(sp)
                     c.set_pair_mode(mode)
+                    c.set_tuning(0, variant)
                     c.generate_particles(n, 7, 0, extent, 10.0)
                     for _ in range(2):
                         c.compute()
@@ -37,7 +39,7 @@ def main():
                         c.compute()
                     ms = c.timer_stop() / steps
                     assert c.last_step_kernel == pa.KERNEL_PAIRS
-                    print(f"mode {mode} exponent {exponent:4.1f} extent {extent:4.1f} n {n:7d}: {ms:9.4f} ms/step  "
+                    print(f"mode {mode} variant {variant:#x} exponent {exponent:4.1f} extent {extent:4.1f} n {n:7d}: {ms:9.4f} ms/step  "
                           f"{n * n / ms / 1e6:9.2f} G pair visits/s", flush=True)
 
 
