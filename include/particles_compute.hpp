@@ -114,6 +114,16 @@ public:
         check(pcl_pack_particles_device(h_, dev_out, first, count));
     }
 
+    // The pair loop over ranges held by several handles: see particles_hip.h.
+    void pack_pair_sources_device(void* dev_out, std::size_t capacity_records)
+    {
+        check(pcl_pack_pair_sources_device(h_, dev_out, capacity_records));
+    }
+    void compute_gathered(const void* dev_sources, std::size_t n_sources)
+    {
+        check(pcl_step_pairs_gathered(h_, dev_sources, n_sources));
+    }
+
     Diagnostics diagnostics()
     {
         Diagnostics d;

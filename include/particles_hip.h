@@ -176,6 +176,29 @@ int pcl_step(pcl_compute* h);
 /* Convenience: set delta_t, then pcl_step. */
 int pcl_step_dt(pcl_compute* h, float delta_t);
 
+/* The pair term across several handles (one per GPU), each holding a
+ * contiguous index range of one global particle set.  The loop of
+ * src/compute.wgsl:115-144 runs over ALL particles, so every frame the ranges
+ * exchange their positions and types:
+ *
+ *   pcl_pack_pair_sources_device writes this handle's latest state as 16-byte
+ *   records (x, y, z as f32, type as u32) in caller order into device memory
+ *   `dev_out`, followed by capacity_records - n padding records (type
+ *   0xFFFFFFFF), so equal-sized blocks can be all-gathered; asynchronous on
+ *   the handle's stream.
+ *
+ *   pcl_step_pairs_gathered is pcl_step with the partners taken from
+ *   `dev_sources`: n_sources such records, the blocks of all ranges
+ *   concatenated in global index order (padding is skipped).  Each particle
+ *   adds its terms in that order, which is the order of a single handle
+ *   holding the whole set, so the sharded result equals the unsharded one bit
+ *   for bit.  Always runs the exact all-pairs kernel.  The buffer must stay
+ *   valid until the step has run on the handle's stream.
+ *
+ * No counterpart in the reference (one device there). */
+int pcl_pack_pair_sources_device(pcl_compute* h, void* dev_out, size_t capacity_records);
+int pcl_step_pairs_gathered(pcl_compute* h, const void* dev_sources, size_t n_sources);
+
 /* Force the general (pair-loop) kernel even when the pair term is provably
  * zero; for equivalence tests.  0 = automatic choice (default). */
 int pcl_force_pair_kernel(pcl_compute* h, int enable);
@@ -265,7 +288,8 @@ enum {
     PCL_STEP_PAIRS          = 2, /* step_pairs_kernel                                       */
     PCL_STEP_STREAM_COUNT   = 3, /* step_stream_kernel that also histograms the field tiles */
     PCL_STEP_STREAM_SCATTER = 4, /* step_scatter_kernel: update + refresh of the tile order */
-    PCL_STEP_PAIRS_BINNED   = 5  /* sort by cut-off cell + step_pairs_binned_kernel            */
+    PCL_STEP_PAIRS_BINNED   = 5, /* sort by cut-off cell + step_pairs_binned_kernel            */
+    PCL_STEP_PAIRS_GATHERED = 6  /* step_pairs_kernel over partner records given by the caller */
 };
 
 /* Per-launch timing: between begin and read every pcl_step is bracketed by a

@@ -17,6 +17,7 @@ PCL_ERR_OUT_OF_RANGE = -4
 
 KERNEL_NONE, KERNEL_STREAM, KERNEL_PAIRS = 0, 1, 2
 STEP_NONE, STEP_STREAM, STEP_PAIRS, STEP_STREAM_COUNT, STEP_STREAM_SCATTER, STEP_PAIRS_BINNED = 0, 1, 2, 3, 4, 5
+STEP_PAIRS_GATHERED = 6
 PAIRS_AUTO, PAIRS_ALL, PAIRS_BINNED = 0, 1, 2
 
 
@@ -60,6 +61,8 @@ SIGNATURES = {
     "pcl_update_sim_params": (_i, [_vp, _vp]),
     "pcl_step": (_i, [_vp]),
     "pcl_step_dt": (_i, [_vp, _f]),
+    "pcl_pack_pair_sources_device": (_i, [_vp, _vp, _sz]),
+    "pcl_step_pairs_gathered": (_i, [_vp, _vp, _sz]),
     "pcl_force_pair_kernel": (_i, [_vp, _i]),
     "pcl_set_pair_mode": (_i, [_vp, _i]),
     "pcl_last_step_kernel": (_i, [_vp]),

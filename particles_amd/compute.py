@@ -103,6 +103,16 @@ class Compute:
         else:
             _lib.check(self._lib.pcl_step_dt(self._h, float(dt)))
 
+    def pack_pair_sources_device(self, dev_out, capacity_records):
+        """Latest (x, y, z, type) records in caller order, padded to
+        ``capacity_records``, into device memory (for the all-gather of the
+        sharded pair step)."""
+        _lib.check(self._lib.pcl_pack_pair_sources_device(self._h, C.c_void_p(int(dev_out)), int(capacity_records)))
+
+    def step_pairs_gathered(self, dev_sources, n_sources):
+        """One update whose pair partners are the gathered records of all ranges."""
+        _lib.check(self._lib.pcl_step_pairs_gathered(self._h, C.c_void_p(int(dev_sources)), int(n_sources)))
+
     def patch_force_grid(self, first_cell, cells):
         g = _as_cells(cells)
         _lib.check(self._lib.pcl_patch_force_grid(self._h, int(first_cell), _ptr(g), g.shape[0]))

@@ -113,6 +113,9 @@ struct pcl_compute {
 
     bool force_pairs = false;
     int pair_mode = 0;                 // PCL_PAIRS_AUTO / _ALL / _BINNED
+    bool gathered_step = false;                // the step in progress takes its partners from ext_sources
+    const pcl::f32x4* ext_sources = nullptr;   // caller's device memory, valid for that step only
+    size_t n_ext_sources = 0;
     bool step_diag = false;
     bool diag_current = false;  // d_diag describes state[cur]
     int last_kernel = PCL_KERNEL_NONE;
@@ -566,7 +569,8 @@ int do_step_impl(pcl_compute* h, int* kind)
 {
     if (int rc = bind(h)) return rc;
     const bool inert = pair_term_inert(h->params);
-    const bool use_pairs = h->force_pairs || !inert;
+    const bool gathered = h->gathered_step;
+    const bool use_pairs = h->force_pairs || !inert || gathered;
     h->last_kernel = use_pairs ? PCL_KERNEL_PAIRS : PCL_KERNEL_STREAM;
     *kind = use_pairs ? PCL_STEP_PAIRS : PCL_STEP_STREAM;
     if (h->n == 0) {
@@ -641,7 +645,7 @@ int do_step_impl(pcl_compute* h, int* kind)
             if (count) h->hist_tiles = T;
             if (count) *kind = PCL_STEP_STREAM_COUNT;
         }
-    } else if (use_binned_pairs(h)) {
+    } else if (!gathered && use_binned_pairs(h)) {
         // Cell-binned pair term: sort by cut-off cell, then sweep the 27 neighbour cells.
         h->hist_valid = false;
         if (h->params_dirty) {
@@ -715,7 +719,24 @@ int do_step_impl(pcl_compute* h, int* kind)
         a.s_near = smallest_square_with([](float len) { return !(len < 0.001f); });
         const float cut = h->params.cut_off_distance;
         a.s_far = smallest_square_with([cut](float len) { return len > cut; });
-        if (small) {
+        a.sources = h->ext_sources;
+        a.n_sources = h->n_ext_sources;
+        if (gathered) {
+            *kind = PCL_STEP_PAIRS_GATHERED;
+            if (small) {
+                if (h->step_diag)
+                    hipLaunchKernelGGL((pcl::step_pairs_kernel<true, 64, true>), dim3(grid), dim3(64), 0, h->stream, a, U);
+                else
+                    hipLaunchKernelGGL((pcl::step_pairs_kernel<false, 64, true>), dim3(grid), dim3(64), 0, h->stream, a, U);
+            } else {
+                if (h->step_diag)
+                    hipLaunchKernelGGL((pcl::step_pairs_kernel<true, pcl::kBlockThreads, true>), dim3(grid),
+                                       dim3(pcl::kBlockThreads), 0, h->stream, a, U);
+                else
+                    hipLaunchKernelGGL((pcl::step_pairs_kernel<false, pcl::kBlockThreads, true>), dim3(grid),
+                                       dim3(pcl::kBlockThreads), 0, h->stream, a, U);
+            }
+        } else if (small) {
             if (h->step_diag)
                 hipLaunchKernelGGL((pcl::step_pairs_kernel<true, 64>), dim3(grid), dim3(64), 0, h->stream, a, U);
             else
@@ -1063,6 +1084,38 @@ int pcl_step_dt(pcl_compute* h, float delta_t)
     h->params.delta_t = delta_t;
     h->params_dirty = true;
     return do_step(h);
+}
+
+int pcl_pack_pair_sources_device(pcl_compute* h, void* dev_out, size_t capacity_records)
+{
+    PCL_REQUIRE(h, "null handle");
+    PCL_REQUIRE(capacity_records >= h->n, "capacity_records is smaller than the particle count");
+    if (capacity_records == 0) return PCL_OK;
+    PCL_REQUIRE(dev_out, "null output pointer");
+    PCL_REQUIRE(reinterpret_cast<uintptr_t>(dev_out) % 16 == 0, "output pointer must be 16-byte aligned");
+    if (int rc = bind(h)) return rc;
+    const uint32_t* slot_of = nullptr;
+    if (int rc = caller_order_map(h, &slot_of)) return rc;
+    hipLaunchKernelGGL(pcl::pack_pair_sources_kernel, dim3(linear_grid(h, capacity_records)), dim3(pcl::kBlockThreads),
+                       0, h->stream, soa_of(h, h->cur), cur_ty(h), slot_of, (unsigned long long)h->n,
+                       (unsigned long long)(capacity_records - h->n), static_cast<pcl::f32x4*>(dev_out));
+    PCL_HIP_TRY(hipGetLastError());
+    return PCL_OK;
+}
+
+int pcl_step_pairs_gathered(pcl_compute* h, const void* dev_sources, size_t n_sources)
+{
+    PCL_REQUIRE(h, "null handle");
+    PCL_REQUIRE(dev_sources || n_sources == 0, "null sources pointer");
+    PCL_REQUIRE(reinterpret_cast<uintptr_t>(dev_sources) % 16 == 0, "sources pointer must be 16-byte aligned");
+    h->gathered_step = true;
+    h->ext_sources = static_cast<const pcl::f32x4*>(dev_sources);
+    h->n_ext_sources = n_sources;
+    const int rc = do_step(h);
+    h->gathered_step = false;
+    h->ext_sources = nullptr;
+    h->n_ext_sources = 0;
+    return rc;
 }
 
 int pcl_force_pair_kernel(pcl_compute* h, int enable)

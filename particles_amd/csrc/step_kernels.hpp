@@ -462,6 +462,10 @@ struct PairArgs {
     // so rejected pairs never pay for the square root.
     float s_near;
     float s_far;
+    // Gathered variant only: the partners, as (x, y, z, type bits) records in
+    // global particle order; records whose type is >= 5 are padding.
+    const f32x4* __restrict__ sources;
+    unsigned long long n_sources;
 };
 
 // One term of wgsl:132-139 for a partner that passed the skip tests.
@@ -489,6 +493,7 @@ __device__ __forceinline__ void pair_term(const f32x4 o, float x, float y, float
 // max-over-lanes(survivors) times instead of once per candidate whenever any
 // lane survives, and each lane still adds its terms in candidate order.  The
 // particle itself is among the candidates and drops out with s = 0 < s_near.
+template <bool PADDED = false>
 __device__ __forceinline__ void sweep_candidates(const f32x4* tile, int cnt, bool live, float x, float y, float z,
                                                  float s_near, float s_far, float exponent, const StepUniforms& U,
                                                  const float* my_polys, float& ax, float& ay, float& az)
@@ -503,7 +508,8 @@ __device__ __forceinline__ void sweep_candidates(const f32x4* tile, int cnt, boo
                     const f32x4 o = tile[sb + k];
                     const float dx = o.x - x, dy = o.y - y, dz = o.z - z;
                     const float s = (dx * dx + dy * dy) + dz * dz;
-                    const bool keep = !(s < s_near) && !(s >= s_far);
+                    bool keep = !(s < s_near) && !(s >= s_far);
+                    if (PADDED) keep = keep && __float_as_uint(o.w) < 5u;
                     mask |= (unsigned long long)keep << k;
                 }
             } else {
@@ -511,7 +517,8 @@ __device__ __forceinline__ void sweep_candidates(const f32x4* tile, int cnt, boo
                     const f32x4 o = tile[sb + k];
                     const float dx = o.x - x, dy = o.y - y, dz = o.z - z;
                     const float s = (dx * dx + dy * dy) + dz * dz;
-                    const bool keep = !(s < s_near) && !(s >= s_far);
+                    bool keep = !(s < s_near) && !(s >= s_far);
+                    if (PADDED) keep = keep && __float_as_uint(o.w) < 5u;
                     mask |= (unsigned long long)keep << k;
                 }
             }
@@ -532,7 +539,14 @@ __device__ __forceinline__ void sweep_candidates(const f32x4* tile, int cnt, boo
 // particle's sum is accumulated in the shader's order j = 0..N-1 (bit-exact;
 // the price is that the parallelism is N lanes, no split of the j range).
 // PB = 64 (one wave per block) spreads small sets over more CUs.
-template <bool DIAG, int PB>
+//
+// GATHERED: the partners come from a.sources (n_sources records of all ranks'
+// particles in global order, padding marked by a type >= 5) instead of this
+// handle's own arrays; the particle's own record is among them and drops out
+// with a zero distance like any coincident partner (wgsl:120-127).  Each sum
+// still runs over j = 0..N-1 of the global set, so a sharded run adds the same
+// terms in the same order as one device holding everything.
+template <bool DIAG, int PB, bool GATHERED = false>
 __global__ __launch_bounds__(PB) void step_pairs_kernel(PairArgs a, StepUniforms U)
 {
     __shared__ f32x4 tile[PB];
@@ -554,19 +568,24 @@ __global__ __launch_bounds__(PB) void step_pairs_kernel(PairArgs a, StepUniforms
     const float* my_polys = &polys[my_ty * 5u * 8u];
     float ax = 0.0f, ay = 0.0f, az = 0.0f;
 
-    for (unsigned long long base = 0; base < a.n; base += PB) {
+    const unsigned long long n_partners = GATHERED ? a.n_sources : a.n;
+    for (unsigned long long base = 0; base < n_partners; base += PB) {
         __syncthreads();
         const unsigned long long j = base + threadIdx.x;
         f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (j < a.n) {
-            t.x = a.src[0][j]; t.y = a.src[1][j]; t.z = a.src[2][j];
-            t.w = __uint_as_float((uint32_t)a.ty[j]);
+        if (j < n_partners) {
+            if (GATHERED) {
+                t = a.sources[j];
+            } else {
+                t.x = a.src[0][j]; t.y = a.src[1][j]; t.z = a.src[2][j];
+                t.w = __uint_as_float((uint32_t)a.ty[j]);
+            }
         }
         tile[threadIdx.x] = t;
         __syncthreads();
-        const unsigned long long rem = a.n - base;
+        const unsigned long long rem = n_partners - base;
         const int cnt = rem < (unsigned long long)PB ? (int)rem : PB;
-        sweep_candidates(tile, cnt, live, x, y, z, a.s_near, a.s_far, exponent, U, my_polys, ax, ay, az);
+        sweep_candidates<GATHERED>(tile, cnt, live, x, y, z, a.s_near, a.s_far, exponent, U, my_polys, ax, ay, az);
     }
 
     DiagAcc acc;
@@ -717,6 +736,25 @@ __global__ __launch_bounds__(kBlockThreads) void pack_aos_kernel(
         *reinterpret_cast<f32x4*>(out[i].pos) = p;
         *reinterpret_cast<f32x4*>(out[i].vel) = v;
         *reinterpret_cast<u32x4*>(&out[i].ty) = t;
+    }
+}
+
+// Partner records of the gathered pair step: (x, y, z, type bits) per particle
+// in caller order, then `pad` records marked as padding (type 0xFFFFFFFF).
+__global__ __launch_bounds__(kBlockThreads) void pack_pair_sources_kernel(
+    StateSoA s, const uint8_t* __restrict__ ty, const uint32_t* __restrict__ slot_of,
+    unsigned long long count, unsigned long long pad, f32x4* __restrict__ out)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x;
+         i < count + pad; i += stride) {
+        f32x4 r = {0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)};
+        if (i < count) {
+            const unsigned long long o = slot_of ? slot_of[i] : i;
+            r.x = s.a[0][o]; r.y = s.a[1][o]; r.z = s.a[2][o];
+            r.w = __uint_as_float((uint32_t)ty[o]);
+        }
+        out[i] = r;
     }
 }
 

@@ -3,12 +3,16 @@
 With the pair term inert every particle depends only on its own state, the
 replicated field and the replicated 912-byte parameter block, so the particle
 set is split into contiguous index ranges, one per rank, with no data-path
-collective.  What does travel, over ``torch.distributed`` (backend "nccl" is
-RCCL over xGMI on ROCm):
+collective.  With the pair term active the loop of src/compute.wgsl:115-144
+runs over ALL particles: every frame the ranks all-gather 16 bytes per particle
+(position and type) and each updates its range against the gathered records in
+global index order, which reproduces the single-device sums bit for bit.  What
+travels, over ``torch.distributed`` (backend "nccl" is RCCL over xGMI on ROCm):
 
 * the field — built on rank 0, replicated with one broadcast at construction,
   after ``update_force_grid`` and (dirty range only) after ``patch_force_grid``
   (the reference re-uploads the whole field every frame: src/main.rs:371-380);
+* with the pair term active, per step one all-gather of 16 B x N;
 * per-step diagnostics — two tiny all-reduces (sum: count, kinetic energy;
   max: max xyz, -min xyz), issued asynchronously so they overlap the next step.
 
@@ -19,6 +23,7 @@ import numpy as np
 
 from .compute import Compute
 from .particle import PARTICLE_DTYPE
+from .sim_params import SimParams
 
 
 def shard_range(n_total, rank, world_size):
@@ -77,6 +82,9 @@ class ShardedCompute:
         if particles is None:
             self.local.generate_particles(self.last - self.first, seed, first_global_index=self.first,
                                           pos_extent=pos_extent, vel_extent=vel_extent)
+        self._params = SimParams()     # the handle starts with SimParams::new(): all curves zero
+        self._pair_active = False
+        self._pair_bufs = None
         self._diag_enabled = False
         # Ring of diagnostics records: an all-reduce in flight owns its record
         # until waited for, so consecutive steps use different ones.
@@ -159,6 +167,45 @@ class ShardedCompute:
     def update_sim_params(self, sim_params):
         """Replicated by value on every rank (src/compute.rs:206-219)."""
         self.local.update_sim_params(sim_params)
+        if not isinstance(sim_params, SimParams):
+            wrapped = SimParams()
+            wrapped.raw = np.asarray(sim_params)
+            sim_params = wrapped
+        self._params = sim_params.copy()
+        self._pair_active = not sim_params.pair_term_inert()
+
+    def _pair_capacity(self):
+        """Records per rank in the all-gather: the largest range, ceil(N / G)."""
+        return -(-self.n_total // self.world_size)
+
+    def _pair_step(self):
+        """One update with the pair term active across ranks: pack (x, y, z,
+        type) of the local range, all-gather, update against all records."""
+        torch, dist = self._torch, self._dist
+        cap = self._pair_capacity()
+        if self._pair_bufs is None or self._pair_bufs[0].shape[0] != cap:
+            self._pair_bufs = (torch.empty((cap, 4), dtype=torch.float32, device=self._comm_device),
+                               torch.empty((cap * self.world_size, 4), dtype=torch.float32, device=self._comm_device))
+        send, recv = self._pair_bufs
+        if self.on_gpu:
+            self.local.pack_pair_sources_device(send.data_ptr(), cap)
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+            self.local.step_pairs_gathered(recv.data_ptr(), recv.shape[0])
+        else:
+            send.copy_(torch.from_numpy(self.local.pack_pair_sources(cap)))
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+            self.local.step_pairs_gathered(recv.numpy(), self.rank * cap)
+
+    def _advance(self, dt=None):
+        if self._pair_active and self._collectives and self.n_total > 0:
+            if dt is not None:      # step(dt) = set delta_t, then one update
+                self._params.delta_t = dt
+                self.local.update_sim_params(self._params)
+            self._pair_step()
+        elif dt is None:
+            self.local.compute()
+        else:
+            self.local.step(dt)
 
     def enable_step_diagnostics(self, enable=True):
         self._diag_enabled = bool(enable)
@@ -167,12 +214,12 @@ class ShardedCompute:
     def compute(self):
         """One update of the local range (src/compute.rs:221-227); with step
         diagnostics enabled, also starts their all-reduce."""
-        self.local.compute()
+        self._advance()
         if self._diag_enabled:
             self._start_diag_allreduce()
 
     def step(self, dt=None):
-        self.local.step(dt)
+        self._advance(dt)
         if self._diag_enabled:
             self._start_diag_allreduce()
 

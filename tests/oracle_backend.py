@@ -57,6 +57,32 @@ class OracleCompute:
             self.sp.delta_t = dt
         self.compute()
 
+    def pack_pair_sources(self, capacity_records):
+        """(x, y, z, type bits) per particle, padded with type 0xFFFFFFFF records."""
+        rec = np.zeros((capacity_records, 4), dtype=np.float32)
+        rec[:, 3].view(np.uint32)[:] = 0xFFFFFFFF
+        n = self.p.shape[0]
+        rec[:n, :3] = self.p["pos"][:, :3]
+        rec[:n, 3].view(np.uint32)[:] = self.p["ty"]
+        return rec
+
+    def step_pairs_gathered(self, records, own_block_start):
+        """Update this range against the gathered records of all ranges;
+        ``own_block_start`` is the record index where this range's block begins."""
+        records = np.ascontiguousarray(records, dtype=np.float32)
+        ty = records[:, 3].view(np.uint32)
+        keep = ty < 5
+        first = int(np.count_nonzero(keep[:own_block_start]))
+        n = self.p.shape[0]
+        full = np.zeros(int(np.count_nonzero(keep)), dtype=O.PARTICLE_DTYPE)
+        full["pos"][:, :3] = records[keep, :3]
+        full["pos"][:, 3] = 1.0
+        full["ty"] = ty[keep]
+        assert np.array_equal(full["pos"][first:first + n, :3], self.p["pos"][:, :3])
+        full[first:first + n] = self.p
+        if n:
+            self.p = O.step_range(self.sp, full, self.g, first, n).copy()
+
     def enable_step_diagnostics(self, enable=True):
         pass
 

@@ -105,6 +105,59 @@ def test_two_rank_sharding_matches_unsharded(tmp_path, oracle):
         assert np.array_equal(r["pos_min"], want_diag["pos_min"])
 
 
+def _pair_scene(pa, O, n):
+    sp = pa.SimParams()
+    sp.delta_t = np.float32(1.0 / 60.0)
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    sp.cut_off_distance = np.float32(1.5)
+    sp.polys[:] = np.random.default_rng(5).uniform(-1, 1, size=(25, 8)).astype(np.float32)
+    particles = O.synth_particles(n, seed=9, pos_extent=4.0, vel_extent=2.0)
+    grid = sp.new_force_grid_centered().get_force_vectors()
+    return sp, particles, grid
+
+
+def _pair_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    import particles_amd as pa
+    from oracle import oracle as O
+    from oracle_backend import OracleCompute
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sp, particles, grid = _pair_scene(pa, O, 301)   # ranges of 150 and 151: one padding record travels
+        sc = pa.ShardedCompute.new(particles.view(pa.PARTICLE_DTYPE), grid if rank == 0 else None,
+                                   compute_cls=OracleCompute)
+        sc.update_sim_params(sp)
+        for _ in range(2):
+            sc.compute()
+        sc.step(1.0 / 120.0)
+        full = sc.gather_particles()
+        np.savez(os.path.join(out_dir, f"pair_rank{rank}.npz"), full=full)
+        sc.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_pair_term_matches_unsharded(tmp_path, oracle):
+    """Pair term active: ranks exchange positions and types every step and
+    reproduce the single-range result byte for byte."""
+    import particles_amd as pa
+    world = 2
+    mp.spawn(_pair_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sp, p, g = _pair_scene(pa, oracle, 301)
+    assert not sp.pair_term_inert()
+    want = oracle.run(sp, p, g, 2)
+    sp.delta_t = np.float32(1.0 / 120.0)
+    want = oracle.run(sp, want, g, 1)
+    for rank in range(world):
+        r = np.load(tmp_path / f"pair_rank{rank}.npz")
+        assert r["full"].tobytes() == want.tobytes()
+
+
 @pytest.mark.parametrize("n,world", [(0, 1), (1, 2), (10, 3), (1001, 2), (1 << 30, 8), (7, 8)])
 def test_shard_ranges_partition_the_set(n, world):
     import particles_amd as pa

@@ -90,6 +90,41 @@ __global__ __launch_bounds__(BLOCK) void copy_kernel(StreamArgs a)
     for (int k = 0; k < 6; ++k) store4<NT>(a.dst[k], g, v[k]);
 }
 
+// Copy of the same byte mix in a chunked layout: chunks of CH particles, each
+// [x CH][y CH][z CH][vx CH][vy CH][vz CH][type CH bytes], one block per chunk.
+template <bool NT, int CH>
+__global__ __launch_bounds__(CH / 4) void copy_chunked_kernel(const char* __restrict__ s, char* __restrict__ d)
+{
+    const size_t chunk = (size_t)CH * 25;
+    const char* sb = s + (size_t)blockIdx.x * chunk;
+    char* db = d + (size_t)blockIdx.x * chunk;
+    f32x4 v[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = load4<NT>(reinterpret_cast<const float*>(sb + (size_t)k * CH * 4), threadIdx.x);
+    const uint32_t t = reinterpret_cast<const uint32_t*>(sb + (size_t)CH * 24)[threadIdx.x];
+    v[0].x += __uint_as_float(t & 1u);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) store4<NT>(reinterpret_cast<float*>(db + (size_t)k * CH * 4), threadIdx.x, v[k]);
+}
+
+// Structural variants of the chunked copy: TYPE 0 = no type stream, 1 = type loaded last, 2 = type loaded first.
+template <int TYPE, int CH, int K>
+__global__ __launch_bounds__(CH / 4) void copy_chunked2_kernel(const char* __restrict__ s, char* __restrict__ d)
+{
+    const size_t chunk = (size_t)CH * (4 * K + 1);
+    const char* sb = s + (size_t)blockIdx.x * chunk;
+    char* db = d + (size_t)blockIdx.x * chunk;
+    f32x4 v[K];
+    uint32_t t = 0;
+    if (TYPE == 2) t = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sb + (size_t)CH * 4 * K) + threadIdx.x);
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = load4<true>(reinterpret_cast<const float*>(sb + (size_t)k * CH * 4), threadIdx.x);
+    if (TYPE == 1) t = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sb + (size_t)CH * 4 * K) + threadIdx.x);
+    if (TYPE) v[0].x += __uint_as_float(t & 1u);
+#pragma unroll
+    for (int k = 0; k < K; ++k) store4<true>(reinterpret_cast<float*>(db + (size_t)k * CH * 4), threadIdx.x, v[k]);
+}
+
 // Plain float4 copy a -> b
 template <bool NT>
 __global__ __launch_bounds__(256) void copy1_kernel(const f32x4* __restrict__ s, f32x4* __restrict__ d, unsigned long long n4)
@@ -310,6 +345,64 @@ int main(int argc, char** argv)
                 if (k < 5 || k == 8 || k == 16) printf("step %3d: %8.4f ms  %8.1f GB/s %7.2f Gp/s\n", k, ms, c.n * 49.0 / ms / 1e6, c.n / ms / 1e6);
             }
         }
+    }
+    if (set == 4) {
+        char* A = slab;
+        char* B = slab + (size_t)6 * arr_bytes;   // second half of the slab
+        for (int rep = 0; rep < 2; ++rep) {
+            float ms = time_ms(c, [&](StreamArgs& a) {
+                const bool f = &a == &c.fwd;
+                hipLaunchKernelGGL((copy_chunked_kernel<true, 2048>), dim3((unsigned)(c.n / 2048)), dim3(512), 0, 0, f ? A : B, f ? B : A);
+            });
+            report("chunked copy CH=2048 (nt)", c, ms);
+            ms = time_ms(c, [&](StreamArgs& a) {
+                const bool f = &a == &c.fwd;
+                hipLaunchKernelGGL((copy_chunked_kernel<true, 1024>), dim3((unsigned)(c.n / 1024)), dim3(256), 0, 0, f ? A : B, f ? B : A);
+            });
+            report("chunked copy CH=1024 (nt)", c, ms);
+            ms = time_ms(c, [&](StreamArgs& a) {
+                const bool f = &a == &c.fwd;
+                hipLaunchKernelGGL((copy_chunked_kernel<false, 2048>), dim3((unsigned)(c.n / 2048)), dim3(512), 0, 0, f ? A : B, f ? B : A);
+            });
+            report("chunked copy CH=2048 (plain)", c, ms);
+            ms = time_ms(c, [&](StreamArgs& a) {
+                hipLaunchKernelGGL((copy_kernel<true, 512>), dim3((unsigned)(c.n / 4 / 512)), dim3(512), 0, 0, a);
+            });
+            report("13-stream copy block 512 (nt)", c, ms);
+        }
+    }
+    if (set == 5) {
+        // one contiguous float4 copy at growing footprints (first half of the slab -> second half)
+        const f32x4* A = (const f32x4*)slab;
+        f32x4* B = (f32x4*)(slab + (size_t)6 * arr_bytes);
+        for (size_t mib = 256; mib <= 6144 && mib * (1u << 20) <= (size_t)6 * arr_bytes; mib += (mib < 1024 ? 256 : 1024)) {
+            const unsigned long long n16 = mib * (1ull << 20) / 16;
+            float ms = time_ms(c, [&](StreamArgs&) {
+                hipLaunchKernelGGL(copy1_kernel<true>, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, A, B, n16);
+            });
+            printf("contiguous nt copy %5zu MiB -> %5zu MiB: %8.4f ms %8.1f GB/s\n", mib, mib, ms, 2.0 * mib * 1048576.0 / ms / 1e6);
+        }
+    }
+    if (set == 6) {
+        char* A = slab;
+        char* B = slab + (size_t)6 * arr_bytes;
+#define RUN2(TYPE, CH, K)                                                                                         \
+        {                                                                                                         \
+            const size_t chunk_bytes = (size_t)CH * (4 * K + 1);                                                  \
+            const size_t half_bytes = (size_t)6 * arr_bytes;                                                      \
+            const unsigned g = (unsigned)std::min<size_t>(c.n * 6 / K / CH, half_bytes / chunk_bytes);            \
+            if ((size_t)g * chunk_bytes > half_bytes) { printf("bounds\n"); return 1; }                           \
+            float ms = time_ms(c, [&](StreamArgs& a) {                                                            \
+                const bool f = &a == &c.fwd;                                                                      \
+                hipLaunchKernelGGL((copy_chunked2_kernel<TYPE, CH, K>), dim3(g), dim3(CH / 4), 0, 0, f ? A : B, f ? B : A); \
+            });                                                                                                   \
+            const double bytes = (double)g * CH * (8.0 * K + (TYPE ? 1 : 0));                                     \
+            printf("chunked type=%d CH=%d K=%d: %8.4f ms %8.1f GB/s\n", TYPE, CH, K, ms, bytes / ms / 1e6);         \
+        }
+        RUN2(0, 2048, 6) RUN2(1, 2048, 6) RUN2(2, 2048, 6)
+        RUN2(0, 256, 6) RUN2(0, 1024, 6) RUN2(0, 4096, 6)
+        RUN2(0, 2048, 1) RUN2(0, 2048, 2) RUN2(0, 2048, 3) RUN2(0, 2048, 4) RUN2(0, 2048, 8) RUN2(0, 2048, 12)
+        RUN2(0, 1024, 1) RUN2(0, 1024, 2) RUN2(0, 1024, 3)
     }
     return 0;
 }
