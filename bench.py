@@ -125,10 +125,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--edits", action="store_true",
                     help="every step a brush (src/cursor.rs, Shift mode) rewrites the cells within falloff_dist of a "
-                         "moving cursor; the dirty list is broadcast and patched before the step")
+                         "moving cursor on the device field; rank 0's cursor record is broadcast before the step")
     ap.add_argument("--force-collectives", action="store_true",
                     help="use the RCCL broadcast/all-reduce path even with one rank (when started by torch.distributed.run)")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: anything libraries print there (RCCL's version banner)
+    # goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -164,23 +170,18 @@ def main():
     diag_on = args.diagnostics == "on"
     sc.enable_step_diagnostics(diag_on)
 
-    brush = grid_host = None
+    brush = None
     if args.edits:
-        # rank 0 owns the host copy of the field and the brush, like the reference's App
-        # (src/main.rs:287-316); the other ranks only receive the dirty cells
-        if rank == 0:
-            grid_host = pa.Grid(field_host[:, :3], dims, pa.Bounds((-RADIUS,) * 3, (2 * RADIUS,) * 3))
-            brush = pa.Brush(pa.EditMode(mode="shift", falloff_dist=1.0, strength=1.0))
-            brush.mouse_down(grid_host, (0.0, 0.0, 0.0))
+        # the brush runs on every replica of the device field; rank 0 owns the cursor, like the
+        # reference's App (src/main.rs:287-316), and only its 64-byte record travels
+        brush = pa.DeviceBrush(sc, pa.EditMode(mode="shift", falloff_dist=1.0, strength=1.0))
+        brush.mouse_down((0.0, 0.0, 0.0))
     frame = [0]
 
     def one_step():
         if args.edits:
-            idx = cells = None
-            if rank == 0:
-                a = 0.05 * frame[0]
-                idx, cells = brush.mouse_moved(grid_host, (0.3 * np.cos(a), 0.3 * np.sin(a), 0.0))
-            sc.patch_force_grid_indexed(idx, cells)
+            a = 0.05 * frame[0]
+            brush.mouse_moved((0.3 * np.cos(a), 0.3 * np.sin(a), 0.0))
             frame[0] += 1
         sc.compute()          # one update of the local range (+ the diagnostics all-reduce when enabled)
 
@@ -276,7 +277,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sp, field_host, args.seed, args.pos_extent)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     sc.close()
     if dist.is_initialized():

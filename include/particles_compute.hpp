@@ -133,6 +133,8 @@ public:
     void enable_step_diagnostics(bool on) { check(pcl_enable_step_diagnostics(h_, on ? 1 : 0)); }
     void set_reorder_interval(int interval) { check(pcl_set_reorder_interval(h_, interval)); }
     void synchronize() { check(pcl_synchronize(h_)); }
+    void set_stream(void* hip_stream) { check(pcl_set_stream(h_, hip_stream)); }
+    void use_null_stream() { check(pcl_use_null_stream(h_)); }
     int last_step_kernel() const { return pcl_last_step_kernel(h_); }
     pcl_compute* handle() { return h_; }
 

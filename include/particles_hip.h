@@ -165,6 +165,59 @@ int pcl_patch_force_grid_indexed(pcl_compute* h, const uint32_t* cell_indices,
 int pcl_patch_force_grid_indexed_device(pcl_compute* h, const void* dev_cell_indices,
                                         const void* dev_cells, size_t count);
 
+/* ---- field brush -----------------------------------------------------------
+ * The editing half of the reference's cursor, run on the device over the
+ * resident field instead of on the host followed by a whole-field upload
+ * (src/main.rs:371-380).  One 64-byte record carries what Cursor and EditMode
+ * hold per event (src/cursor.rs:5-17,144-151). */
+enum { PCL_EDIT_CENTERED = 0, PCL_EDIT_SHIFT = 1, PCL_EDIT_ROTATE = 2 };                 /* src/cursor.rs:124-129 */
+enum { PCL_FALLOFF_ABRUPT = 0, PCL_FALLOFF_LINEAR = 1, PCL_FALLOFF_INVERSE_DISTANCE = 2 }; /* src/cursor.rs:137-142 */
+
+typedef struct pcl_brush_input {
+    float   cursor_pos[3];   /* Cursor::pos                                        */
+    float   falloff_dist;    /* EditMode::falloff_dist                             */
+    float   cam_right[3];    /* Cursor::rot.x (first column),  src/cursor.rs:168   */
+    float   strength;        /* EditMode::strength                                 */
+    float   cam_dir[3];      /* Cursor::rot.z (third column),  src/cursor.rs:167   */
+    int32_t mode;            /* PCL_EDIT_*                                         */
+    int32_t relative;        /* 1 = RelAbE::Relative, 0 = Absolute                 */
+    int32_t falloff;         /* PCL_FALLOFF_*                                      */
+    int32_t reserved[2];
+} pcl_brush_input;
+
+/* Cursor::new + EditMode::default: src/cursor.rs:20-34,206-216. */
+void pcl_brush_input_default(pcl_brush_input* out);
+
+/* Replaces Cursor::mouse_down, src/cursor.rs:105-116: selects the cells whose
+ * centre (Grid::get_positions, src/grid.rs:119-138, bounds (-r, 2r) and
+ * dimensions from the parameter block) lies within falloff_dist of cursor_pos
+ * and remembers their vectors and the cursor position.  Asynchronous.  The
+ * _device variant reads the record from device memory (e.g. a buffer that was
+ * just broadcast to every GPU). */
+int pcl_brush_mouse_down(pcl_compute* h, const pcl_brush_input* in);
+int pcl_brush_mouse_down_device(pcl_compute* h, const void* dev_in);
+
+/* Replaces Cursor::mouse_moved, src/cursor.rs:79-103, with
+ * EditMode::get_vector, src/cursor.rs:158-203: rewrites exactly the selected
+ * cells of the device field.  Does nothing unless a mouse_down is active. */
+int pcl_brush_mouse_moved(pcl_compute* h, const pcl_brush_input* in);
+int pcl_brush_mouse_moved_device(pcl_compute* h, const void* dev_in);
+
+/* Replaces Cursor::mouse_up, src/cursor.rs:118-121. */
+int pcl_brush_mouse_up(pcl_compute* h);
+
+/* The current selection (Cursor::modify_vector_indices, src/cursor.rs:12),
+ * ascending; *count receives its size, at most `capacity` indices are
+ * written.  Synchronises. */
+int pcl_brush_selection(pcl_compute* h, uint32_t* out_indices, size_t capacity, size_t* count);
+
+/* Number of cells of the device field (length of the last whole-field upload). */
+size_t pcl_num_cells(const pcl_compute* h);
+
+/* Reads cells [first_cell, first_cell + count) of the device field (the host
+ * copy of the reference's Grid is not kept up to date by the device brush). */
+int pcl_read_force_grid(pcl_compute* h, float (*out)[4], size_t first_cell, size_t count);
+
 /* Replaces Compute::update_sim_params, src/compute.rs:206-219.  delta_t
  * travels in the block, as in the reference. */
 int pcl_update_sim_params(pcl_compute* h, const pcl_sim_params* params);
@@ -256,6 +309,13 @@ int pcl_debug_cell_indices(pcl_compute* h, uint32_t* out, size_t first, size_t c
 /* Run subsequent work of this handle on `hip_stream` (a hipStream_t owned by
  * the caller, e.g. torch's current stream); NULL restores the internal one. */
 int pcl_set_stream(pcl_compute* h, void* hip_stream);
+
+/* Run subsequent work of this handle on the device's null (legacy default)
+ * stream.  That is the stream PyTorch and its RCCL collectives order against
+ * unless told otherwise (its handle value is 0, which pcl_set_stream takes as
+ * "restore the internal stream"); the handle's internal stream is
+ * non-blocking and is NOT ordered with it. */
+int pcl_use_null_stream(pcl_compute* h);
 
 /* Block until the handle's stream is idle. */
 int pcl_synchronize(pcl_compute* h);

@@ -68,6 +68,11 @@ def load():
     lib.orc_synth_uniform.restype = f
     lib.orc_synth_uniform.argtypes = [u64, u64, u32]
     lib.orc_synth_particles.argtypes = [vp, sz, u64, u64, f, f]
+    lib.orc_edit_mode_default.argtypes = [vp]
+    lib.orc_brush_get_vector.argtypes = [vp] * 8
+    lib.orc_brush_mouse_down.restype = sz
+    lib.orc_brush_mouse_down.argtypes = [vp, vp, vp, f, vp, vp, sz]
+    lib.orc_brush_mouse_moved.argtypes = [vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]
     assert lib.orc_sizeof_particle() == 48 and lib.orc_sizeof_sim_params() == SIM_PARAMS_BYTES
     _lib = lib
     return lib
@@ -196,3 +201,48 @@ def synth_particles(n, seed, first_global_index=0, pos_extent=2.0, vel_extent=10
 
 def max_threads():
     return int(load().orc_max_threads())
+
+
+# ---- field brush (src/cursor.rs) -------------------------------------------
+EDIT_MODE_DTYPE = np.dtype([("mode", np.int32), ("relative", np.int32), ("falloff", np.int32),
+                            ("falloff_dist", np.float32), ("strength", np.float32)])
+MODES = {"centered": 0, "shift": 1, "rotate": 2}
+FALLOFFS = {"abrupt": 0, "linear": 1, "inverse_distance": 2}
+
+
+def edit_mode(mode="shift", relative=True, falloff="abrupt", falloff_dist=1.0, strength=1.0):
+    m = np.zeros(1, dtype=EDIT_MODE_DTYPE)
+    m["mode"], m["relative"], m["falloff"] = MODES[mode], int(relative), FALLOFFS[falloff]
+    m["falloff_dist"], m["strength"] = falloff_dist, strength
+    return m
+
+
+def _f3(v):
+    return np.ascontiguousarray(v, dtype=np.float32).reshape(3)
+
+
+def brush_get_vector(m, v, v_pos, md_pos, cursor_pos, cam_right, cam_dir):
+    out = np.zeros(3, dtype=np.float32)
+    load().orc_brush_get_vector(_p(m), _p(_f3(v)), _p(_f3(v_pos)), _p(_f3(md_pos)), _p(_f3(cursor_pos)),
+                                _p(_f3(cam_right)), _p(_f3(cam_dir)), _p(out))
+    return out
+
+
+def brush_mouse_down(params, grid, cursor_pos, falloff_dist):
+    """Selected cell indices (ascending) and their vectors at mouse-down."""
+    g = _grid(grid)
+    idx = np.zeros(g.shape[0], dtype=np.uint32)
+    vec = np.zeros((g.shape[0], 3), dtype=np.float32)
+    n = load().orc_brush_mouse_down(_p(_params_buf(params)), _p(g), _p(_f3(cursor_pos)), float(falloff_dist),
+                                    _p(idx), _p(vec), g.shape[0])
+    return idx[:n].copy(), vec[:n].copy()
+
+
+def brush_mouse_moved(params, grid, m, indices, md_vectors, md_pos, cursor_pos, cam_right=(1, 0, 0), cam_dir=(0, 0, 1)):
+    """Returns the field after the edit (input untouched)."""
+    g = _grid(grid).copy()
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    vec = np.ascontiguousarray(md_vectors, dtype=np.float32).reshape(-1, 3)
+    load().orc_brush_mouse_moved(_p(_params_buf(params)), _p(g), _p(m), _p(idx), _p(vec), idx.shape[0],
+                                 _p(_f3(md_pos)), _p(_f3(cursor_pos)), _p(_f3(cam_right)), _p(_f3(cam_dir)))
+    return g

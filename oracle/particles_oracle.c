@@ -446,3 +446,125 @@ void orc_synth_particles(orc_particle* out, size_t n, uint64_t seed, uint64_t fi
         out[i] = p;
     }
 }
+
+/* ------------------------------------------------------------------------
+ * Field brush: src/cursor.rs:79-116,158-203 (host-side Rust in the reference;
+ * f32 arithmetic without contraction).  cgmath 0.18 (Cargo.lock) supplies the
+ * vector operations, restated here from its published definitions:
+ *   dot(a,b)      = a.x*b.x + a.y*b.y + a.z*b.z      (element-wise product, summed x+y+z)
+ *   magnitude(v)  = sqrt(dot(v,v)),  distance(a,b) = magnitude(b - a)
+ *   normalize(v)  = v * (1.0 / magnitude(v))          (normalize_to(1.0))
+ *   cross(a,b)    = (a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x)
+ *   s * v, v * s  = component-wise
+ * cam_rot is given as its three columns: right (Matrix3::x), up (::y),
+ * dir (::z); src/cursor.rs:167-168 reads .z and .x.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+    int32_t mode;      /* 0 Centered, 1 Shift, 2 Rotate: src/cursor.rs:124-129 */
+    int32_t relative;  /* 1 Relative, 0 Absolute:        src/cursor.rs:131-135 */
+    int32_t falloff;   /* 0 Abrupt, 1 Linear, 2 InverseDistance: src/cursor.rs:137-142 */
+    float   falloff_dist;
+    float   strength;
+} orc_edit_mode;
+
+/* EditMode::default: src/cursor.rs:206-216 */
+void orc_edit_mode_default(orc_edit_mode* m)
+{
+    m->mode = 1; m->relative = 1; m->falloff = 0; m->falloff_dist = 1.0f; m->strength = 1.0f;
+}
+
+static float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static float magnitude3(const float* v) { return sqrtf(dot3(v, v)); }
+static void normalize3(const float* v, float* out)
+{
+    const float s = 1.0f / magnitude3(v);
+    out[0] = v[0] * s; out[1] = v[1] * s; out[2] = v[2] * s;
+}
+
+/* EditMode::get_vector: src/cursor.rs:158-203 */
+void orc_brush_get_vector(const orc_edit_mode* m, const float* v, const float* v_pos, const float* md_pos,
+                          const float* cursor_pos, const float* cam_right, const float* cam_dir, float* out)
+{
+    float res[3];
+    if (m->mode == 0) {                       /* Centered: :170-173 */
+        const float d[3] = {cursor_pos[0] - v_pos[0], cursor_pos[1] - v_pos[1], cursor_pos[2] - v_pos[2]};
+        normalize3(d, res);
+    } else if (m->mode == 1) {                /* Shift: :174 */
+        for (int k = 0; k < 3; ++k) res[k] = cursor_pos[k] - md_pos[k];
+    } else {                                  /* Rotate: :175-190 */
+        if (cursor_pos[0] == md_pos[0] && cursor_pos[1] == md_pos[1] && cursor_pos[2] == md_pos[2]) {
+            for (int k = 0; k < 3; ++k) res[k] = v[k];
+        } else {
+            const float dc[3] = {cursor_pos[0] - md_pos[0], cursor_pos[1] - md_pos[1], cursor_pos[2] - md_pos[2]};
+            const float d[3] = {v_pos[0] - md_pos[0], v_pos[1] - md_pos[1], v_pos[2] - md_pos[2]};
+            float dv[3];
+            normalize3(d, dv);
+            const float dir[3] = {dv[1] * cam_dir[2] - dv[2] * cam_dir[1],
+                                  dv[2] * cam_dir[0] - dv[0] * cam_dir[2],
+                                  dv[0] * cam_dir[1] - dv[1] * cam_dir[0]};
+            const float s = dot3(dc, cam_right);
+            for (int k = 0; k < 3; ++k) res[k] = dir[k] * s;
+        }
+    }
+    const float res_len = magnitude3(res);    /* :192 */
+    if (m->falloff == 1) {                    /* Linear: :195-199 */
+        const float d[3] = {md_pos[0] - v_pos[0], md_pos[1] - v_pos[1], md_pos[2] - v_pos[2]};
+        const float factor = magnitude3(d) / m->falloff_dist;
+        const float s = 1.0f - factor;
+        for (int k = 0; k < 3; ++k) res[k] = s * res[k];
+    } else if (m->falloff == 2) {             /* InverseDistance: :200 */
+        const float s = m->falloff_dist / (res_len + 1.0f);
+        for (int k = 0; k < 3; ++k) res[k] = s * res[k];
+    }
+    for (int k = 0; k < 3; ++k) out[k] = res[k] * m->strength;   /* :202 */
+}
+
+static void cell_position(const orc_sim_params* p, size_t flat, float* out)
+{
+    const size_t ny = p->force_grid_dimensions[1], nz = p->force_grid_dimensions[2];
+    const size_t ix = flat / (ny * nz), iy = (flat / nz) % ny, iz = flat % nz;
+    const float left = -p->bounding_volume_radius, dir = 2.0f * p->bounding_volume_radius;
+    out[0] = left + dir * (((float)ix + 0.5f) / (float)p->force_grid_dimensions[0]);   /* src/grid.rs:124-131 */
+    out[1] = left + dir * (((float)iy + 0.5f) / (float)ny);
+    out[2] = left + dir * (((float)iz + 0.5f) / (float)nz);
+}
+
+/* Cursor::mouse_down: src/cursor.rs:105-116.  Writes the selected cell indices
+ * (ascending) and their current vectors; returns how many (never more than
+ * `capacity` are written). */
+size_t orc_brush_mouse_down(const orc_sim_params* p, const float (*grid)[4], const float* cursor_pos,
+                            float falloff_dist, uint32_t* out_indices, float (*out_vectors)[3], size_t capacity)
+{
+    const size_t n = (size_t)p->force_grid_dimensions[0] * p->force_grid_dimensions[1] * p->force_grid_dimensions[2];
+    size_t count = 0;
+    for (size_t ix = 0; ix < n; ++ix) {
+        float vpos[3];
+        cell_position(p, ix, vpos);
+        const float d[3] = {vpos[0] - cursor_pos[0], vpos[1] - cursor_pos[1], vpos[2] - cursor_pos[2]};   /* pos.distance(vpos) */
+        if (magnitude3(d) < falloff_dist) {
+            if (count < capacity) {
+                out_indices[count] = (uint32_t)ix;
+                for (int k = 0; k < 3; ++k) out_vectors[count][k] = grid[ix][k];
+            }
+            ++count;
+        }
+    }
+    return count;
+}
+
+/* Cursor::mouse_moved: src/cursor.rs:79-103; rewrites the selected cells of
+ * `grid` in place (w stays 1.0: src/grid.rs:97-103). */
+void orc_brush_mouse_moved(const orc_sim_params* p, float (*grid)[4], const orc_edit_mode* m,
+                           const uint32_t* indices, const float (*md_vectors)[3], size_t count,
+                           const float* md_pos, const float* cursor_pos, const float* cam_right, const float* cam_dir)
+{
+    for (size_t k = 0; k < count; ++k) {
+        const size_t ix = indices[k];
+        float vpos[3], disp[3];
+        cell_position(p, ix, vpos);
+        orc_brush_get_vector(m, grid[ix], vpos, md_pos, cursor_pos, cam_right, cam_dir, disp);
+        for (int c = 0; c < 3; ++c)
+            grid[ix][c] = m->relative ? disp[c] + md_vectors[k][c] : disp[c];   /* :97-100 */
+        grid[ix][3] = 1.0f;
+    }
+}

@@ -9,11 +9,11 @@ from .grid import Bounds, Grid
 from .sim_params import SIM_PARAMS_DTYPE, SimParams
 from ._lib import PclError, KERNEL_NONE, KERNEL_STREAM, KERNEL_PAIRS
 from .compute import Compute
-from .cursor import Brush, EditMode
+from .cursor import BRUSH_INPUT_DTYPE, Brush, DeviceBrush, EditMode
 from .sharded import ShardedCompute, shard_range
 
 __all__ = [
     "PARTICLE_DTYPE", "MASS_WRAP_DTYPE", "NUM_TYPES", "empty_particles", "lattice_particles", "random_particles",
     "POLY7_DTYPE", "Poly7", "Bounds", "Grid", "SIM_PARAMS_DTYPE", "SimParams",
-    "PclError", "KERNEL_NONE", "KERNEL_STREAM", "KERNEL_PAIRS", "Compute", "ShardedCompute", "shard_range", "Brush", "EditMode",
+    "PclError", "KERNEL_NONE", "KERNEL_STREAM", "KERNEL_PAIRS", "Compute", "ShardedCompute", "shard_range", "Brush", "DeviceBrush", "EditMode", "BRUSH_INPUT_DTYPE",
 ]

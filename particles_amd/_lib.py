@@ -58,6 +58,15 @@ SIGNATURES = {
     "pcl_patch_force_grid_device": (_i, [_vp, _sz, _vp, _sz]),
     "pcl_patch_force_grid_indexed": (_i, [_vp, _vp, _vp, _sz]),
     "pcl_patch_force_grid_indexed_device": (_i, [_vp, _vp, _vp, _sz]),
+    "pcl_brush_input_default": (None, [_vp]),
+    "pcl_brush_mouse_down": (_i, [_vp, _vp]),
+    "pcl_brush_mouse_down_device": (_i, [_vp, _vp]),
+    "pcl_brush_mouse_moved": (_i, [_vp, _vp]),
+    "pcl_brush_mouse_moved_device": (_i, [_vp, _vp]),
+    "pcl_brush_mouse_up": (_i, [_vp]),
+    "pcl_brush_selection": (_i, [_vp, _vp, _sz, C.POINTER(_sz)]),
+    "pcl_read_force_grid": (_i, [_vp, _vp, _sz, _sz]),
+    "pcl_num_cells": (_sz, [_vp]),
     "pcl_update_sim_params": (_i, [_vp, _vp]),
     "pcl_step": (_i, [_vp]),
     "pcl_step_dt": (_i, [_vp, _f]),
@@ -76,6 +85,7 @@ SIGNATURES = {
     "pcl_diagnostics_device": (_i, [_vp, _vp]),
     "pcl_debug_cell_indices": (_i, [_vp, _vp, _sz, _sz]),
     "pcl_set_stream": (_i, [_vp, _vp]),
+    "pcl_use_null_stream": (_i, [_vp]),
     "pcl_synchronize": (_i, [_vp]),
     "pcl_timer_start": (_i, [_vp]),
     "pcl_timer_stop": (_i, [_vp, C.POINTER(_f)]),
@@ -91,11 +101,28 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """Keep the process on ONE HIP runtime.  PyTorch-ROCm ships its own copy of
+    libamdhip64 and asks for it by file name; this library asks for the soname
+    libamdhip64.so.7.  Loaded in the order "this library, then torch" the two
+    requests resolve to two different files, and the second runtime to
+    initialise finds no GPU.  Loading torch's copy first (when torch is
+    installed; torch itself is not imported) makes both requests resolve to it."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load libparticles_hip.so (built in-tree by ``make``); raises if absent."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make` at the repository root "

@@ -14,6 +14,7 @@ import numpy as np
 
 from . import _lib
 from .particle import PARTICLE_DTYPE
+from .cursor import BRUSH_INPUT_DTYPE
 from .sim_params import SIM_PARAMS_DTYPE, SimParams
 
 
@@ -76,6 +77,10 @@ class Compute:
     def num_particles(self):
         return int(self._lib.pcl_num_particles(self._h))
 
+    @property
+    def num_cells(self):
+        return int(self._lib.pcl_num_cells(self._h))
+
     def upload_particles(self, particles):
         p = _as_particles(particles)
         _lib.check(self._lib.pcl_upload_particles(self._h, _ptr(p), p.shape[0]))
@@ -102,6 +107,49 @@ class Compute:
             _lib.check(self._lib.pcl_step(self._h))
         else:
             _lib.check(self._lib.pcl_step_dt(self._h, float(dt)))
+
+    # -- field brush (src/cursor.rs) --------------------------------------
+    @staticmethod
+    def _brush_record(record):
+        r = np.ascontiguousarray(record)
+        if r.dtype != BRUSH_INPUT_DTYPE or r.size != 1:
+            raise TypeError("expected one BRUSH_INPUT_DTYPE record (EditMode.record)")
+        return r
+
+    def brush_mouse_down(self, record):
+        """Cursor::mouse_down (src/cursor.rs:105-116) on the device field."""
+        r = self._brush_record(record)
+        _lib.check(self._lib.pcl_brush_mouse_down(self._h, _ptr(r)))
+
+    def brush_mouse_moved(self, record):
+        """Cursor::mouse_moved (src/cursor.rs:79-103) on the device field."""
+        r = self._brush_record(record)
+        _lib.check(self._lib.pcl_brush_mouse_moved(self._h, _ptr(r)))
+
+    def brush_mouse_down_device(self, dev_record):
+        _lib.check(self._lib.pcl_brush_mouse_down_device(self._h, C.c_void_p(int(dev_record))))
+
+    def brush_mouse_moved_device(self, dev_record):
+        _lib.check(self._lib.pcl_brush_mouse_moved_device(self._h, C.c_void_p(int(dev_record))))
+
+    def brush_mouse_up(self):
+        _lib.check(self._lib.pcl_brush_mouse_up(self._h))
+
+    def brush_selection(self):
+        """Selected cell indices, ascending (Cursor::modify_vector_indices)."""
+        n = C.c_size_t(0)
+        _lib.check(self._lib.pcl_brush_selection(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint32)
+        if n.value:
+            _lib.check(self._lib.pcl_brush_selection(self._h, _ptr(out), out.shape[0], C.byref(n)))
+        return out
+
+    def read_force_grid(self, first_cell=0, count=None):
+        """Cells of the device field as (count, 4) float32."""
+        count = self.num_cells - first_cell if count is None else int(count)
+        out = np.zeros((count, 4), dtype=np.float32)
+        _lib.check(self._lib.pcl_read_force_grid(self._h, _ptr(out), int(first_cell), count))
+        return out
 
     def pack_pair_sources_device(self, dev_out, capacity_records):
         """Latest (x, y, z, type) records in caller order, padded to
@@ -208,7 +256,16 @@ class Compute:
         return int(self._lib.pcl_step_count(self._h))
 
     def set_stream(self, hip_stream):
-        _lib.check(self._lib.pcl_set_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else 0)))
+        """Run on the caller's stream: a ``hipStream_t`` handle value (e.g.
+        ``torch.cuda.current_stream().cuda_stream``).  The value 0 is the
+        device's null stream — PyTorch's default stream — and is adopted as
+        such; ``None`` restores the handle's internal stream."""
+        if hip_stream is None:
+            _lib.check(self._lib.pcl_set_stream(self._h, None))
+        elif int(hip_stream) == 0:
+            _lib.check(self._lib.pcl_use_null_stream(self._h))
+        else:
+            _lib.check(self._lib.pcl_set_stream(self._h, C.c_void_p(int(hip_stream))))
 
     def synchronize(self):
         _lib.check(self._lib.pcl_synchronize(self._h))

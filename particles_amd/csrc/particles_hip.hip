@@ -12,6 +12,7 @@
 // (reference ping-pong: src/compute.rs:147-180,221-227).
 #include "step_kernels.hpp"
 #include "reorder_kernels.hpp"
+#include "brush_kernels.hpp"
 
 #include "particles_hip.h"
 
@@ -105,6 +106,12 @@ struct pcl_compute {
 
     pcl::f32x4* field = nullptr;
     size_t n_cells = 0;
+    // field brush (src/cursor.rs): selection made by mouse_down, used by mouse_moved
+    bool brush_down = false;
+    pcl::BrushState* d_brush_state = nullptr;
+    uint32_t* d_brush_index = nullptr;
+    pcl::f32x4* d_brush_vector = nullptr;
+    size_t brush_capacity = 0;
     size_t field_capacity = 0;
 
     pcl_sim_params params;
@@ -813,6 +820,78 @@ int upload_field(pcl_compute* h, size_t first_cell, const void* src, size_t coun
     return PCL_OK;
 }
 
+// Geometry of the field as the host-side Grid sees it: dimensions from the
+// parameter block, bounds (-r, 2r) as in src/sim_params.rs:33-45.
+int field_geometry(const pcl_compute* h, pcl::FieldGeometry* G)
+{
+    const uint32_t* d = h->params.force_grid_dimensions;
+    PCL_REQUIRE((uint64_t)d[0] * d[1] * d[2] == (uint64_t)h->n_cells,
+                "force_grid_dimensions of the parameters do not match the uploaded field");
+    PCL_REQUIRE(h->n_cells <= 0xFFFFFFFFull, "field too large for the brush");
+    G->nx = d[0]; G->ny = d[1]; G->nz = d[2];
+    G->left = -h->params.bounding_volume_radius;
+    G->dir = 2.0f * h->params.bounding_volume_radius;
+    return PCL_OK;
+}
+
+int reserve_brush(pcl_compute* h)
+{
+    if (!h->d_brush_state) PCL_HIP_TRY(hipMalloc((void**)&h->d_brush_state, sizeof(pcl::BrushState)));
+    if (h->brush_capacity >= h->n_cells) return PCL_OK;
+    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->d_brush_index) PCL_HIP_TRY(hipFree(h->d_brush_index));
+    if (h->d_brush_vector) PCL_HIP_TRY(hipFree(h->d_brush_vector));
+    h->d_brush_index = nullptr;
+    h->d_brush_vector = nullptr;
+    h->brush_capacity = 0;
+    PCL_HIP_TRY(hipMalloc((void**)&h->d_brush_index, h->n_cells * sizeof(uint32_t)));
+    PCL_HIP_TRY(hipMalloc((void**)&h->d_brush_vector, h->n_cells * sizeof(pcl::f32x4)));
+    h->brush_capacity = h->n_cells;
+    return PCL_OK;
+}
+
+pcl::BrushInput brush_input_of(const pcl_brush_input* in)
+{
+    static_assert(sizeof(pcl_brush_input) == sizeof(pcl::BrushInput), "brush record layout");
+    pcl::BrushInput r;
+    std::memset(&r, 0, sizeof r);
+    if (in) std::memcpy(&r, in, sizeof r);
+    return r;
+}
+
+int brush_mouse_down(pcl_compute* h, const pcl_brush_input* host_in, const void* dev_in)
+{
+    if (int rc = bind(h)) return rc;
+    pcl::FieldGeometry G;
+    if (int rc = field_geometry(h, &G)) return rc;
+    if (int rc = reserve_brush(h)) return rc;
+    PCL_HIP_TRY(hipMemsetAsync(h->d_brush_state, 0, sizeof(pcl::BrushState), h->stream));
+    hipLaunchKernelGGL(pcl::brush_select_kernel, dim3(linear_grid(h, h->n_cells)), dim3(pcl::kBlockThreads), 0,
+                       h->stream, brush_input_of(host_in), static_cast<const pcl::BrushInput*>(dev_in), G,
+                       (uint32_t)h->n_cells, (const pcl::f32x4*)h->field, h->d_brush_state, h->d_brush_index,
+                       h->d_brush_vector);
+    PCL_HIP_TRY(hipGetLastError());
+    h->brush_down = true;
+    return PCL_OK;
+}
+
+int brush_mouse_moved(pcl_compute* h, const pcl_brush_input* host_in, const void* dev_in)
+{
+    if (!h->brush_down) return PCL_OK;   // src/cursor.rs:82: nothing happens without a mouse-down
+    if (int rc = bind(h)) return rc;
+    pcl::FieldGeometry G;
+    if (int rc = field_geometry(h, &G)) return rc;
+    PCL_REQUIRE(h->brush_capacity >= h->n_cells, "the field was replaced by a larger one since mouse_down");
+    // the selection size lives on the device: a fixed grid strides over it
+    const uint32_t grid = std::min<uint32_t>(linear_grid(h, h->n_cells), 1024u);
+    hipLaunchKernelGGL(pcl::brush_apply_kernel, dim3(grid), dim3(pcl::kBlockThreads), 0, h->stream,
+                       brush_input_of(host_in), static_cast<const pcl::BrushInput*>(dev_in), G, h->field,
+                       (const pcl::BrushState*)h->d_brush_state, (const uint32_t*)h->d_brush_index,
+                       (const pcl::f32x4*)h->d_brush_vector);
+    PCL_HIP_TRY(hipGetLastError());
+    return PCL_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -843,7 +922,7 @@ int pcl_destroy(pcl_compute* h)
 {
     if (!h) return PCL_OK;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->stream);   // a null handle names the device's null stream
     if (h->own_stream && h->own_stream != h->stream) (void)hipStreamSynchronize(h->own_stream);
     free_particles(h);
     if (h->field) (void)hipFree(h->field);
@@ -851,6 +930,9 @@ int pcl_destroy(pcl_compute* h)
     if (h->d_partials) (void)hipFree(h->d_partials);
     if (h->d_diag) (void)hipFree(h->d_diag);
     if (h->d_hist) (void)hipFree(h->d_hist);
+    if (h->d_brush_state) (void)hipFree(h->d_brush_state);
+    if (h->d_brush_index) (void)hipFree(h->d_brush_index);
+    if (h->d_brush_vector) (void)hipFree(h->d_brush_vector);
     for (hipEvent_t e : h->timing_events) (void)hipEventDestroy(e);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
@@ -993,6 +1075,7 @@ int pcl_update_force_grid(pcl_compute* h, const float (*force_grid)[4], size_t n
     PCL_REQUIRE(force_grid != nullptr && n_cells >= 1, "pcl_update_force_grid: the force grid is empty");
     PCL_REQUIRE(n_cells <= 0xFFFFFFFFull, "pcl_update_force_grid: more than 2^32 - 1 cells");
     if (int rc = reserve_field(h, n_cells)) return rc;
+    if (n_cells != h->n_cells) h->brush_down = false;   // a selection indexes the field it was made on
     h->n_cells = n_cells;
     return upload_field(h, 0, force_grid, n_cells, false);
 }
@@ -1003,6 +1086,7 @@ int pcl_update_force_grid_device(pcl_compute* h, const void* dev_force_grid, siz
     PCL_REQUIRE(dev_force_grid != nullptr && n_cells >= 1, "pcl_update_force_grid_device: the force grid is empty");
     PCL_REQUIRE(n_cells <= 0xFFFFFFFFull, "pcl_update_force_grid_device: more than 2^32 - 1 cells");
     if (int rc = reserve_field(h, n_cells)) return rc;
+    if (n_cells != h->n_cells) h->brush_down = false;   // a selection indexes the field it was made on
     h->n_cells = n_cells;
     return upload_field(h, 0, dev_force_grid, n_cells, true);
 }
@@ -1059,6 +1143,95 @@ int pcl_patch_force_grid_indexed_device(pcl_compute* h, const void* dev_cell_ind
                        h->field, (unsigned long long)h->n_cells, reinterpret_cast<const uint32_t*>(dev_cell_indices),
                        reinterpret_cast<const pcl::f32x4*>(dev_cells), (unsigned long long)count);
     PCL_HIP_TRY(hipGetLastError());
+    return PCL_OK;
+}
+
+void pcl_brush_input_default(pcl_brush_input* out)
+{
+    if (!out) return;
+    std::memset(out, 0, sizeof *out);
+    out->cam_right[0] = 1.0f;   // Cursor::new: rot = identity, src/cursor.rs:20-34
+    out->cam_dir[2] = 1.0f;
+    out->mode = PCL_EDIT_SHIFT;   // EditMode::default, src/cursor.rs:206-216
+    out->relative = 1;
+    out->falloff = PCL_FALLOFF_ABRUPT;
+    out->falloff_dist = 1.0f;
+    out->strength = 1.0f;
+}
+
+static int check_brush_input(const pcl_brush_input* in)
+{
+    PCL_REQUIRE(in, "null brush record");
+    PCL_REQUIRE(in->mode >= PCL_EDIT_CENTERED && in->mode <= PCL_EDIT_ROTATE, "unknown edit mode");
+    PCL_REQUIRE(in->falloff >= PCL_FALLOFF_ABRUPT && in->falloff <= PCL_FALLOFF_INVERSE_DISTANCE, "unknown falloff");
+    return PCL_OK;
+}
+
+int pcl_brush_mouse_down(pcl_compute* h, const pcl_brush_input* in)
+{
+    PCL_REQUIRE(h, "null handle");
+    if (int rc = check_brush_input(in)) return rc;
+    return brush_mouse_down(h, in, nullptr);
+}
+
+int pcl_brush_mouse_down_device(pcl_compute* h, const void* dev_in)
+{
+    PCL_REQUIRE(h && dev_in, "null handle or record");
+    return brush_mouse_down(h, nullptr, dev_in);
+}
+
+int pcl_brush_mouse_moved(pcl_compute* h, const pcl_brush_input* in)
+{
+    PCL_REQUIRE(h, "null handle");
+    if (int rc = check_brush_input(in)) return rc;
+    return brush_mouse_moved(h, in, nullptr);
+}
+
+int pcl_brush_mouse_moved_device(pcl_compute* h, const void* dev_in)
+{
+    PCL_REQUIRE(h && dev_in, "null handle or record");
+    return brush_mouse_moved(h, nullptr, dev_in);
+}
+
+int pcl_brush_mouse_up(pcl_compute* h)
+{
+    PCL_REQUIRE(h, "null handle");
+    h->brush_down = false;   // src/cursor.rs:118-121
+    return PCL_OK;
+}
+
+int pcl_brush_selection(pcl_compute* h, uint32_t* out_indices, size_t capacity, size_t* count)
+{
+    PCL_REQUIRE(h && count, "null handle or count");
+    *count = 0;
+    if (!h->brush_down) return PCL_OK;
+    if (int rc = bind(h)) return rc;
+    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+    pcl::BrushState st;
+    PCL_HIP_TRY(hipMemcpy(&st, h->d_brush_state, sizeof st, hipMemcpyDeviceToHost));
+    *count = st.count;
+    const size_t take = std::min<size_t>(st.count, capacity);
+    if (take) {
+        PCL_REQUIRE(out_indices, "null output");
+        std::vector<uint32_t> all(st.count);
+        PCL_HIP_TRY(hipMemcpy(all.data(), h->d_brush_index, all.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        std::sort(all.begin(), all.end());   // the device appends in arbitrary order
+        std::memcpy(out_indices, all.data(), take * sizeof(uint32_t));
+    }
+    return PCL_OK;
+}
+
+size_t pcl_num_cells(const pcl_compute* h) { return h ? h->n_cells : 0; }
+
+int pcl_read_force_grid(pcl_compute* h, float (*out)[4], size_t first_cell, size_t count)
+{
+    PCL_REQUIRE(h, "null handle");
+    if (int rc = check_range(first_cell, count, h->n_cells, "pcl_read_force_grid")) return rc;
+    if (count == 0) return PCL_OK;
+    PCL_REQUIRE(out, "null output");
+    if (int rc = bind(h)) return rc;
+    PCL_HIP_TRY(hipMemcpyAsync(out, h->field + first_cell, count * sizeof(pcl::f32x4), hipMemcpyDeviceToHost, h->stream));
+    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
     return PCL_OK;
 }
 
@@ -1273,6 +1446,14 @@ int pcl_set_stream(pcl_compute* h, void* hip_stream)
     hipStream_t next = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
     if (next != h->stream) PCL_HIP_TRY(hipStreamSynchronize(h->stream));  // keep work ordered across the switch
     h->stream = next;
+    return PCL_OK;
+}
+
+int pcl_use_null_stream(pcl_compute* h)
+{
+    if (int rc = bind(h)) return rc;
+    if (h->stream != nullptr) PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+    h->stream = nullptr;   // the device's null stream
     return PCL_OK;
 }
 

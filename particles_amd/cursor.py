@@ -13,9 +13,24 @@ import numpy as np
 
 F = np.float32
 
+# The 64-byte record the device brush takes (pcl_brush_input).
+BRUSH_INPUT_DTYPE = np.dtype([
+    ("cursor_pos", np.float32, 3), ("falloff_dist", np.float32),
+    ("cam_right", np.float32, 3), ("strength", np.float32),
+    ("cam_dir", np.float32, 3), ("mode", np.int32),
+    ("relative", np.int32), ("falloff", np.int32), ("reserved", np.int32, 2)])
+assert BRUSH_INPUT_DTYPE.itemsize == 64
+
 
 def _norm(v):
-    return np.sqrt((v * v).sum(axis=-1, dtype=F)).astype(F)
+    """cgmath magnitude: sqrt(x*x + y*y + z*z), summed in that order."""
+    v = np.asarray(v, dtype=F)
+    return np.sqrt((v[..., 0] * v[..., 0] + v[..., 1] * v[..., 1]) + v[..., 2] * v[..., 2]).astype(F)
+
+
+def _normalize(v):
+    """cgmath normalize: v * (1 / magnitude(v))."""
+    return (v * (F(1.0) / _norm(v))[..., None]).astype(F)
 
 
 class EditMode:
@@ -30,6 +45,17 @@ class EditMode:
         self.mode, self.relative, self.falloff = mode, bool(relative), falloff
         self.falloff_dist, self.strength = F(falloff_dist), F(strength)
 
+    def record(self, cursor_pos, cam_rot=None):
+        """The device brush's input record for this mode, a cursor position and
+        a rotation matrix whose columns are the camera's right/up/direction."""
+        rot = np.eye(3, dtype=F) if cam_rot is None else np.asarray(cam_rot, dtype=F)
+        r = np.zeros(1, dtype=BRUSH_INPUT_DTYPE)
+        r["cursor_pos"], r["cam_right"], r["cam_dir"] = np.asarray(cursor_pos, dtype=F), rot[:, 0], rot[:, 2]
+        r["falloff_dist"], r["strength"] = self.falloff_dist, self.strength
+        r["mode"], r["falloff"] = self.MODES.index(self.mode), self.FALLOFFS.index(self.falloff)
+        r["relative"] = int(self.relative)
+        return r
+
     def get_vector(self, v, v_pos, md_pos, cursor_pos, cam_rot):
         """Vectorised over cells: ``v`` current vectors (n,3), ``v_pos`` their
         positions (n,3); ``md_pos`` the cursor at mouse-down, ``cursor_pos`` the
@@ -43,8 +69,7 @@ class EditMode:
         cam_dir, cam_right = cam_rot[:, 2], cam_rot[:, 0]
         with np.errstate(all="ignore"):
             if self.mode == "centered":
-                d = cursor_pos[None, :] - v_pos
-                res = d / _norm(d)[:, None]
+                res = _normalize(cursor_pos[None, :] - v_pos)
             elif self.mode == "shift":
                 res = np.broadcast_to(cursor_pos - md_pos, v.shape).astype(F)
             else:  # rotate
@@ -52,9 +77,11 @@ class EditMode:
                     res = v.copy()
                 else:
                     dc = cursor_pos - md_pos
-                    dv = v_pos - md_pos[None, :]
-                    dv = dv / _norm(dv)[:, None]
-                    res = np.cross(dv, cam_dir[None, :]).astype(F) * F(np.dot(dc, cam_right))
+                    dv = _normalize(v_pos - md_pos[None, :])
+                    cross = np.stack([dv[:, 1] * cam_dir[2] - dv[:, 2] * cam_dir[1],
+                                      dv[:, 2] * cam_dir[0] - dv[:, 0] * cam_dir[2],
+                                      dv[:, 0] * cam_dir[1] - dv[:, 1] * cam_dir[0]], axis=1).astype(F)
+                    res = cross * F((dc[0] * cam_right[0] + dc[1] * cam_right[1]) + dc[2] * cam_right[2])
             res_len = _norm(res)
             if self.falloff == "linear":
                 mag = _norm(md_pos[None, :] - v_pos)
@@ -105,3 +132,27 @@ class Brush:
         """src/cursor.rs:118-121."""
         self.mouse_down_on = None
         self.modify_vector_indices = np.zeros(0, dtype=np.int64)
+
+
+class DeviceBrush:
+    """The same three events as ``Brush``, executed on the device field of a
+    ``Compute`` or ``ShardedCompute`` (src/cursor.rs:79-122): nothing but the
+    64-byte cursor record leaves the host."""
+
+    def __init__(self, compute, edit_mode=None):
+        self.compute = compute
+        self.edit_mode = edit_mode or EditMode()
+        self.rot = np.eye(3, dtype=F)
+
+    def mouse_down(self, pos, rot=None):
+        if rot is not None:
+            self.rot = np.asarray(rot, dtype=F)
+        self.compute.brush_mouse_down(self.edit_mode.record(pos, self.rot))
+
+    def mouse_moved(self, pos, rot=None):
+        if rot is not None:
+            self.rot = np.asarray(rot, dtype=F)
+        self.compute.brush_mouse_moved(self.edit_mode.record(pos, self.rot))
+
+    def mouse_up(self):
+        self.compute.brush_mouse_up()

@@ -71,5 +71,5 @@ class Grid:
         (src/grid.rs:109-117), ascending."""
         pos = self.get_positions()[:, :3]
         d = pos - np.asarray(center, dtype=np.float32)[None, :]
-        dist = np.sqrt((d * d).sum(axis=1, dtype=np.float32))
+        dist = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])
         return np.nonzero(dist < np.float32(radius))[0]

@@ -22,6 +22,7 @@ single-GPU backend each rank instantiates for its range.
 import numpy as np
 
 from .compute import Compute
+from .cursor import BRUSH_INPUT_DTYPE
 from .particle import PARTICLE_DTYPE
 from .sim_params import SimParams
 
@@ -82,6 +83,8 @@ class ShardedCompute:
         if particles is None:
             self.local.generate_particles(self.last - self.first, seed, first_global_index=self.first,
                                           pos_extent=pos_extent, vel_extent=vel_extent)
+        self._brush_ring = None
+        self._brush_slot = 0
         self._params = SimParams()     # the handle starts with SimParams::new(): all curves zero
         self._pair_active = False
         self._pair_bufs = None
@@ -162,6 +165,47 @@ class ShardedCompute:
         else:
             host = buf.numpy()
             self.local.patch_force_grid_indexed(host[n * 4:].view(np.uint32), host[:n * 4].view(np.float32).reshape(n, 4))
+
+    # -- field brush ------------------------------------------------------
+    def _replicate_brush_record(self, record):
+        """Rank 0's 64-byte cursor record on every rank: a device tensor on
+        the GPU path (consumed by the kernels without a host round trip), a
+        host record otherwise."""
+        torch, dist = self._torch, self._dist
+        if not self._collectives:
+            return record
+        if self._brush_ring is None:
+            self._brush_ring = [torch.zeros(64, dtype=torch.uint8, device=self._comm_device) for _ in range(self._RING)]
+        self._brush_slot = (self._brush_slot + 1) % self._RING
+        t = self._brush_ring[self._brush_slot]
+        if self.rank == 0:
+            t.copy_(torch.from_numpy(np.ascontiguousarray(record).view(np.uint8).reshape(64).copy()))
+        dist.broadcast(t, src=0, group=self.group)
+        return t if self.on_gpu else t.numpy().view(BRUSH_INPUT_DTYPE)
+
+    def brush_mouse_down(self, record):
+        """Cursor::mouse_down (src/cursor.rs:105-116) on every replica of the
+        field; ``record`` is taken from rank 0 (others may pass ``None``)."""
+        r = self._replicate_brush_record(record)
+        if self.on_gpu and self._collectives:
+            self.local.brush_mouse_down_device(r.data_ptr())
+        else:
+            self.local.brush_mouse_down(r)
+
+    def brush_mouse_moved(self, record):
+        """Cursor::mouse_moved (src/cursor.rs:79-103): every rank rewrites the
+        same cells of its replica, so only the 64-byte record travels."""
+        r = self._replicate_brush_record(record)
+        if self.on_gpu and self._collectives:
+            self.local.brush_mouse_moved_device(r.data_ptr())
+        else:
+            self.local.brush_mouse_moved(r)
+
+    def brush_mouse_up(self):
+        self.local.brush_mouse_up()
+
+    def read_force_grid(self, first_cell=0, count=None):
+        return self.local.read_force_grid(first_cell, count)
 
     # -- parameters and stepping -----------------------------------------
     def update_sim_params(self, sim_params):

@@ -98,3 +98,27 @@ class OracleCompute:
 
     def close(self):
         pass
+
+    # -- field brush: the oracle's restatement of src/cursor.rs ------------
+    def brush_mouse_down(self, record):
+        r = np.ascontiguousarray(record).reshape(1)
+        self._md_pos = r["cursor_pos"][0].copy()
+        self._sel, self._md_vec = O.brush_mouse_down(self.sp, self.g, self._md_pos, float(r["falloff_dist"][0]))
+        self._brush_down = True
+
+    def brush_mouse_moved(self, record):
+        if not getattr(self, "_brush_down", False):
+            return
+        r = np.ascontiguousarray(record).reshape(1)
+        m = np.zeros(1, dtype=O.EDIT_MODE_DTYPE)
+        for k in ("mode", "relative", "falloff", "falloff_dist", "strength"):
+            m[k] = r[k]
+        self.g = O.brush_mouse_moved(self.sp, self.g, m, self._sel, self._md_vec, self._md_pos,
+                                     r["cursor_pos"][0], r["cam_right"][0], r["cam_dir"][0])
+
+    def brush_mouse_up(self):
+        self._brush_down = False
+
+    def read_force_grid(self, first_cell=0, count=None):
+        count = self.g.shape[0] - first_cell if count is None else count
+        return self.g[first_cell:first_cell + count].copy()

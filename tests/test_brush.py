@@ -100,3 +100,165 @@ def test_brush_patch_reaches_the_device(oracle):
         assert_particles_bit_equal(c.read_particles(), cur, "brush edits")
         with pytest.raises(pa.PclError):
             c.patch_force_grid_indexed([1000], np.ones((1, 4), dtype=F))
+
+
+# ---- the oracle's restatement of the brush, the numpy mirror and the device brush ----
+
+MODES = ("centered", "shift", "rotate")
+FALLOFFS = ("abrupt", "linear", "inverse_distance")
+
+
+def _rot(seed):
+    """A rotation matrix (columns: right, up, direction)."""
+    q, _ = np.linalg.qr(np.random.default_rng(seed).normal(size=(3, 3)))
+    return q.astype(F)
+
+
+def _random_field(sp, seed):
+    d = sp.force_grid_dimensions
+    g = np.ones((d[0] * d[1] * d[2], 4), dtype=F)
+    g[:, :3] = np.random.default_rng(seed).uniform(-2, 2, size=(g.shape[0], 3)).astype(F)
+    return g
+
+
+def test_oracle_brush_known_answers(oracle):
+    """Hand-derived values of src/cursor.rs:158-203 for one cell."""
+    O = oracle
+    v, v_pos, md, cur = (9.0, 9.0, 9.0), (1.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 2.0, 0.0)
+    right, direction = (1.0, 0.0, 0.0), (0.0, 0.0, 1.0)
+    # Shift: cursor - md_pos, times strength
+    assert np.array_equal(O.brush_get_vector(O.edit_mode("shift", strength=0.5), v, v_pos, md, cur, right, direction),
+                          np.array([0.5, 1.0, 0.0], dtype=F))
+    # Centered: unit vector from the cell to the cursor = (0, 1, 0)
+    assert np.array_equal(O.brush_get_vector(O.edit_mode("centered"), v, v_pos, md, cur, right, direction),
+                          np.array([0.0, 1.0, 0.0], dtype=F))
+    # Rotate: dv = (1,0,0); dv x dir = (0*1-0*0, 0*0-1*1, 0) = (0,-1,0); dc . right = 1
+    assert np.array_equal(O.brush_get_vector(O.edit_mode("rotate"), v, v_pos, md, cur, right, direction),
+                          np.array([0.0, -1.0, 0.0], dtype=F))
+    # Rotate with the cursor still at the mouse-down position keeps the vector
+    assert np.array_equal(O.brush_get_vector(O.edit_mode("rotate"), v, v_pos, md, md, right, direction),
+                          np.array(v, dtype=F))
+    # Linear falloff: |md - v_pos| = 1, falloff_dist 4 -> factor 0.75
+    assert np.array_equal(O.brush_get_vector(O.edit_mode("shift", falloff="linear", falloff_dist=4.0), v, v_pos, md,
+                                             (0.0, 2.0, 0.0), right, direction), np.array([0.0, 1.5, 0.0], dtype=F))
+    # InverseDistance: |res| = 3 -> falloff_dist / (3 + 1) = 0.5
+    assert np.array_equal(O.brush_get_vector(O.edit_mode("shift", falloff="inverse_distance", falloff_dist=2.0), v, v_pos,
+                                             md, (0.0, 3.0, 0.0), right, direction), np.array([0.0, 1.5, 0.0], dtype=F))
+
+
+def test_oracle_mouse_down_selects_the_default_scene_cells(oracle):
+    sp = pa.SimParams()
+    g = sp.new_force_grid_centered().get_force_vectors()
+    idx, vec = oracle.brush_mouse_down(sp, g, (0.0, 0.0, 0.0), 1.8)
+    # the 8 cells around the origin: centres at (+-1, +-1, +-1), distance sqrt(3) < 1.8
+    want = [x * 100 + y * 10 + z for x in (4, 5) for y in (4, 5) for z in (4, 5)]
+    assert idx.tolist() == want
+    assert np.array_equal(vec, g[idx, :3])
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("falloff", FALLOFFS)
+@pytest.mark.parametrize("relative", (True, False))
+def test_numpy_brush_equals_oracle_bit_for_bit(oracle, mode, falloff, relative):
+    sp = pa.SimParams()
+    sp.force_grid_dimensions = (12, 9, 7)
+    field = _random_field(sp, 3)
+    em = pa.EditMode(mode=mode, relative=relative, falloff=falloff, falloff_dist=4.5, strength=0.7)
+    rot = _rot(1)
+    grid = pa.Grid(field[:, :3].copy(), sp.force_grid_dimensions, pa.Bounds((-10,) * 3, (20,) * 3))
+    b = pa.Brush(em)
+    md = (1.3, -2.1, 0.4)
+    b.mouse_down(grid, md, rot)
+    idx, vec = oracle.brush_mouse_down(sp, field, md, 4.5)
+    assert np.array_equal(b.modify_vector_indices, idx) and idx.size > 20
+    want = field
+    m = oracle.edit_mode(mode, relative, falloff, 4.5, 0.7)
+    for cursor in ((1.3, -2.1, 0.4), (2.0, -1.5, 0.1), (0.2, 0.3, -0.9)):
+        b.mouse_moved(grid, cursor)
+        want = oracle.brush_mouse_moved(sp, want, m, idx, vec, md, cursor, rot[:, 0], rot[:, 2])
+        assert grid.grid.tobytes() == want[:, :3].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("falloff", FALLOFFS)
+@pytest.mark.parametrize("relative", (True, False))
+def test_device_brush_equals_oracle_bit_for_bit(oracle, mode, falloff, relative):
+    sp = pa.SimParams()
+    sp.force_grid_dimensions = (40, 33, 5)
+    field = _random_field(sp, 11)
+    rot = _rot(2)
+    md = (1.3, -2.1, 0.4)
+    em = pa.EditMode(mode=mode, relative=relative, falloff=falloff, falloff_dist=3.5, strength=1.3)
+    with pa.Compute.new(pa.empty_particles(0), field) as c:
+        c.update_sim_params(sp)
+        b = pa.DeviceBrush(c, em)
+        b.mouse_moved((5.0, 5.0, 5.0))                     # no mouse-down yet: nothing happens
+        assert c.read_force_grid().tobytes() == field.tobytes()
+        b.mouse_down(md, rot)
+        idx, vec = oracle.brush_mouse_down(sp, field, md, 3.5)
+        assert np.array_equal(c.brush_selection(), idx) and idx.size > 50
+        want = field
+        m = oracle.edit_mode(mode, relative, falloff, 3.5, 1.3)
+        for cursor in (md, (2.0, -1.5, 0.1), (0.2, 0.3, -0.9)):
+            b.mouse_moved(cursor)
+            want = oracle.brush_mouse_moved(sp, want, m, idx, vec, md, cursor, rot[:, 0], rot[:, 2])
+            assert c.read_force_grid().tobytes() == want.tobytes()
+        b.mouse_up()
+        b.mouse_moved((9.0, 9.0, 9.0))
+        assert c.read_force_grid().tobytes() == want.tobytes()
+        assert c.brush_selection().size == 0
+
+
+@pytest.mark.gpu
+def test_device_brush_then_steps_match_oracle(oracle):
+    """The config-5 frame: brush edit on the device field, then one update."""
+    sp = pa.SimParams()
+    sp.delta_t = F(1.0 / 60.0)
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    sp.force_grid_dimensions = (64, 64, 1)
+    field = _random_field(sp, 5)
+    p = oracle.synth_particles(30000, seed=2, pos_extent=20.0, vel_extent=10.0)
+    em = pa.EditMode(falloff_dist=2.0)
+    m = oracle.edit_mode(falloff_dist=2.0)
+    with pa.Compute.new(p, field) as c:
+        c.update_sim_params(sp)
+        b = pa.DeviceBrush(c, em)
+        b.mouse_down((0.0, 0.0, 0.0))
+        idx, vec = oracle.brush_mouse_down(sp, field, (0.0, 0.0, 0.0), 2.0)
+        cur, g = p, field
+        for k in range(5):
+            cursor = (0.3 * np.cos(0.05 * k), 0.3 * np.sin(0.05 * k), 0.0)
+            b.mouse_moved(cursor)
+            c.compute()
+            g = oracle.brush_mouse_moved(sp, g, m, idx, vec, (0.0, 0.0, 0.0), cursor)
+            cur = oracle.step(sp, cur, g, mode=oracle.MODE_SKIP_INERT)
+        assert_particles_bit_equal(c.read_particles(), cur, "device brush + steps")
+        assert c.read_force_grid().tobytes() == g.tobytes()
+
+
+@pytest.mark.gpu
+def test_device_brush_argument_checks_and_field_replacement(oracle):
+    sp = pa.SimParams()
+    field = sp.new_force_grid_centered().get_force_vectors()
+    with pa.Compute.new(pa.empty_particles(0), field) as c:
+        c.update_sim_params(sp)
+        r = pa.EditMode(falloff_dist=1.8).record((0.0, 0.0, 0.0))
+        bad = r.copy()
+        bad["mode"] = 7
+        with pytest.raises(pa.PclError):
+            c.brush_mouse_down(bad)
+        sp2 = pa.SimParams()
+        sp2.force_grid_dimensions = (3, 3, 3)           # 27 cells, but 1000 are uploaded
+        c.update_sim_params(sp2)
+        with pytest.raises(pa.PclError):
+            c.brush_mouse_down(r)
+        c.update_sim_params(sp)
+        c.brush_mouse_down(r)
+        assert c.brush_selection().size == 8
+        c.update_force_grid(np.ones((27, 4), dtype=F))  # a different field: the selection is dropped
+        c.update_sim_params(sp2)
+        c.brush_mouse_moved(pa.EditMode().record((1.0, 1.0, 1.0)))
+        assert np.array_equal(c.read_force_grid(), np.ones((27, 4), dtype=F))
+        with pytest.raises(pa.PclError):
+            c.read_force_grid(20, 8)

@@ -141,3 +141,34 @@ def test_sharded_pair_path_all_gather_over_rccl(oracle, one_rank_rccl):
     sp.delta_t = np.float32(1.0 / 120.0)
     want = oracle.run(sp, want, g, 1)
     assert_particles_bit_equal(got, want, "sharded pair path (all-gather) over RCCL")
+
+
+def test_sharded_device_brush_over_rccl(oracle, one_rank_rccl):
+    """Config-5 frame through the sharded layer: the cursor record is broadcast
+    as device bytes and consumed by the brush kernels, then one update."""
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    sp.force_grid_dimensions = (64, 64, 1)
+    g = scene_swirl_field(64, 64, 1, 10.0, seed=6)
+    p = oracle.synth_particles(20000, seed=12, pos_extent=20.0, vel_extent=10.0)
+    em = pa.EditMode(mode="rotate", falloff="inverse_distance", falloff_dist=2.5, strength=0.8)
+    m = oracle.edit_mode("rotate", True, "inverse_distance", 2.5, 0.8)
+    sc = pa.ShardedCompute.new(p.view(pa.PARTICLE_DTYPE), g, force_collectives=True)
+    try:
+        sc.update_sim_params(sp)
+        brush = pa.DeviceBrush(sc, em)
+        brush.mouse_down((0.5, -0.5, 0.0))
+        idx, vec = oracle.brush_mouse_down(sp, g, (0.5, -0.5, 0.0), 2.5)
+        want_p, want_g = p, g
+        for k in range(4):
+            cursor = (0.5 + 0.2 * k, -0.5 + 0.1 * k, 0.0)
+            brush.mouse_moved(cursor)
+            sc.compute()
+            want_g = oracle.brush_mouse_moved(sp, want_g, m, idx, vec, (0.5, -0.5, 0.0), cursor)
+            want_p = oracle.step(sp, want_p, want_g, mode=oracle.MODE_SKIP_INERT)
+        got_p, got_g = sc.gather_particles(), sc.read_force_grid()
+    finally:
+        sc.close()
+    assert got_g.tobytes() == want_g.tobytes()
+    assert_particles_bit_equal(got_p, want_p, "sharded device brush over RCCL")

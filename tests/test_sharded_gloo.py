@@ -158,6 +158,59 @@ def test_two_rank_pair_term_matches_unsharded(tmp_path, oracle):
         assert r["full"].tobytes() == want.tobytes()
 
 
+def _brush_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    import particles_amd as pa
+    from oracle import oracle as O
+    from oracle_backend import OracleCompute
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sp = pa.SimParams()
+        sp.delta_t = np.float32(1.0 / 60.0)
+        particles = O.synth_particles(500, seed=4, pos_extent=20.0, vel_extent=10.0).view(pa.PARTICLE_DTYPE)
+        grid0 = sp.new_force_grid_centered().get_force_vectors()
+        sc = pa.ShardedCompute.new(particles, grid0 if rank == 0 else None, compute_cls=OracleCompute)
+        sc.update_sim_params(sp)
+        em = pa.EditMode(mode="centered", falloff="linear", falloff_dist=4.0, strength=2.0)
+        # only rank 0 knows where the cursor is
+        sc.brush_mouse_down(em.record((1.0, 2.0, 3.0)) if rank == 0 else None)
+        for k in range(3):
+            sc.brush_mouse_moved(em.record((1.0 + k, 2.0, 3.0 - k)) if rank == 0 else None)
+            sc.compute()
+        sc.brush_mouse_up()
+        sc.brush_mouse_moved(em.record((0.0, 0.0, 0.0)) if rank == 0 else None)   # no effect
+        np.savez(os.path.join(out_dir, f"brush_rank{rank}.npz"), full=sc.gather_particles(), field=sc.read_force_grid())
+        sc.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_brush_record_broadcast(tmp_path, oracle):
+    """The brush runs on every replica of the field from rank 0's 64-byte record."""
+    import particles_amd as pa
+    world = 2
+    mp.spawn(_brush_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sp = pa.SimParams()
+    sp.delta_t = np.float32(1.0 / 60.0)
+    p = oracle.synth_particles(500, seed=4, pos_extent=20.0, vel_extent=10.0)
+    g = sp.new_force_grid_centered().get_force_vectors()
+    m = oracle.edit_mode("centered", True, "linear", 4.0, 2.0)
+    idx, vec = oracle.brush_mouse_down(sp, g, (1.0, 2.0, 3.0), 4.0)
+    assert idx.size == 28
+    for k in range(3):
+        g = oracle.brush_mouse_moved(sp, g, m, idx, vec, (1.0, 2.0, 3.0), (1.0 + k, 2.0, 3.0 - k))
+        p = oracle.step(sp, p, g, mode=oracle.MODE_SKIP_INERT)
+    for rank in range(world):
+        r = np.load(tmp_path / f"brush_rank{rank}.npz")
+        assert r["field"].tobytes() == g.tobytes()
+        assert r["full"].tobytes() == p.tobytes()
+
+
 @pytest.mark.parametrize("n,world", [(0, 1), (1, 2), (10, 3), (1001, 2), (1 << 30, 8), (7, 8)])
 def test_shard_ranges_partition_the_set(n, world):
     import particles_amd as pa
