@@ -32,6 +32,43 @@ extern "C" {
     fn pcl_read_particles(h: *mut PclCompute, out: *mut c_void, first: usize, count: usize) -> c_int;
     fn pcl_pack_particles_device(h: *mut PclCompute, dev_out: *mut c_void, first: usize, count: usize) -> c_int;
     fn pcl_synchronize(h: *mut PclCompute) -> c_int;
+    fn pcl_brush_input_default(out: *mut BrushInput);
+    fn pcl_brush_mouse_down(h: *mut PclCompute, input: *const BrushInput) -> c_int;
+    fn pcl_brush_mouse_moved(h: *mut PclCompute, input: *const BrushInput) -> c_int;
+    fn pcl_brush_mouse_up(h: *mut PclCompute) -> c_int;
+    fn pcl_read_force_grid(h: *mut PclCompute, out: *mut [f32; 4], first_cell: usize, count: usize) -> c_int;
+}
+
+/// What `Cursor` and `EditMode` hold per mouse event (src/cursor.rs:5-17,144-151),
+/// as the 64-byte record of `pcl_brush_input`.
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct BrushInput {
+    pub cursor_pos: [f32; 3],
+    pub falloff_dist: f32,
+    /// `Cursor::rot.x` (src/cursor.rs:168)
+    pub cam_right: [f32; 3],
+    pub strength: f32,
+    /// `Cursor::rot.z` (src/cursor.rs:167)
+    pub cam_dir: [f32; 3],
+    /// 0 Centered, 1 Shift, 2 Rotate (src/cursor.rs:124-129)
+    pub mode: i32,
+    /// 1 Relative, 0 Absolute (src/cursor.rs:131-135)
+    pub relative: i32,
+    /// 0 Abrupt, 1 Linear, 2 InverseDistance (src/cursor.rs:137-142)
+    pub falloff: i32,
+    pub reserved: [i32; 2],
+}
+
+impl Default for BrushInput {
+    /// `Cursor::new` + `EditMode::default`: src/cursor.rs:20-34,206-216.
+    fn default() -> Self {
+        let mut r = std::mem::MaybeUninit::<BrushInput>::uninit();
+        unsafe {
+            pcl_brush_input_default(r.as_mut_ptr());
+            r.assume_init()
+        }
+    }
 }
 
 fn check(rc: c_int) {
@@ -109,6 +146,29 @@ impl Compute {
 
     pub fn synchronize(&mut self) {
         check(unsafe { pcl_synchronize(self.handle) });
+    }
+
+    /// `Cursor::mouse_down` (src/cursor.rs:105-116) on the device field.
+    pub fn brush_mouse_down(&mut self, input: &BrushInput) {
+        check(unsafe { pcl_brush_mouse_down(self.handle, input) });
+    }
+
+    /// `Cursor::mouse_moved` (src/cursor.rs:79-103) on the device field; replaces the
+    /// host rewrite and the whole-field upload of src/main.rs:371-380.
+    pub fn brush_mouse_moved(&mut self, input: &BrushInput) {
+        check(unsafe { pcl_brush_mouse_moved(self.handle, input) });
+    }
+
+    /// `Cursor::mouse_up` (src/cursor.rs:118-121).
+    pub fn brush_mouse_up(&mut self) {
+        check(unsafe { pcl_brush_mouse_up(self.handle) });
+    }
+
+    /// The device field, e.g. for drawing the vectors (src/grid.rs:149-170).
+    pub fn read_force_grid(&mut self, first_cell: usize, count: usize) -> Vec<[f32; 4]> {
+        let mut out = vec![[0.0f32; 4]; count];
+        check(unsafe { pcl_read_force_grid(self.handle, out.as_mut_ptr(), first_cell, count) });
+        out
     }
 }
 
