@@ -333,7 +333,10 @@ __device__ __forceinline__ void store4(float* base, unsigned long long group, f3
 // consecutive particles (one 16-byte access per array per lane); the grid is
 // one tile per block, or a smaller persistent grid striding over the tiles
 // when the field is staged in LDS.
-constexpr int kStreamThreads = 512;  // 8 waves
+#ifndef PCL_STREAM_THREADS
+#define PCL_STREAM_THREADS 512   // 8 waves
+#endif
+constexpr int kStreamThreads = PCL_STREAM_THREADS;
 constexpr int kStreamTile = kStreamThreads * kParticlesPerLane;
 
 // COUNT: also histogram the field tile of every OUTPUT position into a.hist
