@@ -282,6 +282,14 @@ def test_full_size_slices_match_oracle(oracle):
         assert c.diagnostics()["count"] == n
 
 
+def test_one_billion_particles_slices_match_oracle(oracle):
+    """2^30 particles on one GPU (4 GiB per array: byte offsets beyond 32 bits),
+    one full refresh cycle of the tile order; 2^31 passes the same check when
+    run by hand (tests/big_sizes_check.py 31)."""
+    import big_sizes_check
+    big_sizes_check.check([30])
+
+
 def test_cpp_host_mirror_matches_oracle(oracle, tmp_path):
     """include/particles_compute.hpp driven like the reference's App
     (per frame: update_force_grid, update_sim_params, compute)."""
