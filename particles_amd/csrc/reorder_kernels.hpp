@@ -123,6 +123,19 @@ struct ScatterLds {
     }
 };
 
+// Barrier for hand-offs that go through LDS only.  __syncthreads() also waits
+// for the wave's outstanding global loads and stores (vmcnt(0)); in the scatter
+// kernels that would drain every array's scattered stores before the next
+// array may be staged (measured: two thirds of the wave cycles parked).  Here
+// only LDS traffic is ordered; nothing in these kernels hands global data from
+// one wave of the block to another.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // After every thread has added its particles to slot[] (lds_rank_add): turn the
 // per-bin counts into local start positions, reserve each non-empty bin's run of
 // global slots with one atomic add, and leave in slot[b] the offset that maps a
@@ -144,7 +157,7 @@ __device__ __forceinline__ void scatter_plan(const ScatterLds& L, uint32_t n_bin
         if (lane >= d) incl += v;
     }
     if (lane == 63) wave_total[wave] = incl;
-    __syncthreads();
+    lds_barrier();
     uint32_t run = incl - sum;
     for (int w = 0; w < wave; ++w) run += wave_total[w];
     for (uint32_t i = 0; i < per; ++i) {
@@ -156,7 +169,7 @@ __device__ __forceinline__ void scatter_plan(const ScatterLds& L, uint32_t n_bin
             run += c;
         }
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // Regroup one per-particle value through LDS and write it out: every thread
@@ -169,7 +182,7 @@ __device__ __forceinline__ void scatter_array(uint32_t* stage, const uint32_t lp
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (k < live) stage[lpos[k]] = __builtin_bit_cast(uint32_t, val[k]);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t l = threadIdx.x + (uint32_t)i * kStreamThreads;
@@ -230,7 +243,7 @@ __device__ __forceinline__ void scatter_write(const ReorderArgs& a, const Scatte
         else cnt = a.n - n_groups * 4ull;   // the appended tail block
         n_local_sh = (uint32_t)cnt;
     }
-    __syncthreads();
+    lds_barrier();
     const uint32_t n_local = n_local_sh;
     uint32_t out_slot[4];
 #pragma unroll
@@ -249,7 +262,7 @@ __device__ __forceinline__ void scatter_write(const ReorderArgs& a, const Scatte
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (k < live) L.stage_ty[lpos[k]] = (uint8_t)((t4 >> (8 * k)) & 0xFFu);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t l = threadIdx.x + (uint32_t)i * kStreamThreads;
@@ -264,8 +277,6 @@ __global__ __launch_bounds__(kStreamThreads) void reorder_scatter_kernel(Reorder
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const ScatterLds L(lds_raw, T.n_bins);
-    for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) L.slot[b] = 0u;
-    __syncthreads();
 
     const unsigned long long n_groups = a.n / 4ull;
     const unsigned long long g = (unsigned long long)blockIdx.x * kStreamThreads + threadIdx.x;
@@ -279,13 +290,16 @@ __global__ __launch_bounds__(kStreamThreads) void reorder_scatter_kernel(Reorder
     f32x4 V[6];
     uint32_t t4 = 0u, orig[4] = {0u, 0u, 0u, 0u};
     scatter_load(a, g, tail, full, is_tail, V, t4, orig);
+    // the loads are in flight while the bin counters are cleared
+    for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) L.slot[b] = 0u;
+    lds_barrier();
     uint32_t key[4], rank[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {   // every lane takes part: lds_rank_add is a wave-wide operation
         key[k] = k < live ? tile_key(U, T, V[0][k], V[1][k], V[2][k], V[3][k], V[4][k], V[5][k]) : 0u;
         rank[k] = lds_rank_add(L.slot, key[k], k < live);
     }
-    __syncthreads();
+    lds_barrier();
     scatter_write(a, L, T.n_bins, V, t4, orig, key, rank, live);
 }
 
@@ -306,8 +320,6 @@ __global__ __launch_bounds__(kStreamThreads) void step_scatter_kernel(StepScatte
     const ReorderArgs& a = sa.r;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const ScatterLds L(lds_raw, T.n_bins);
-    for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) L.slot[b] = 0u;
-    __syncthreads();
 
     const unsigned long long n_groups = a.n / 4ull;
     const unsigned long long g = (unsigned long long)blockIdx.x * kStreamThreads + threadIdx.x;
@@ -322,6 +334,9 @@ __global__ __launch_bounds__(kStreamThreads) void step_scatter_kernel(StepScatte
     f32x4 V[6];
     uint32_t t4 = 0u, orig[4] = {0u, 0u, 0u, 0u};
     scatter_load(a, g, tail, full, is_tail, V, t4, orig);
+    // the loads are in flight while the bin counters are cleared
+    for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) L.slot[b] = 0u;
+    lds_barrier();
     uint32_t key[4], rank[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {   // every lane takes part: lds_rank_add is a wave-wide operation
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(kStreamThreads) void step_scatter_kernel(StepScatte
             if (DIAG) acc.add(m, x, y, z, vx, vy, vz);
         }
     }
-    __syncthreads();
+    lds_barrier();
     scatter_write(a, L, T.n_bins, V, t4, orig, key, rank, live);
     if (DIAG) block_reduce_store<kStreamThreads>(acc, sa.partials + blockIdx.x);
 }
