@@ -95,6 +95,8 @@ public:
 
     // compute(): src/compute.rs:221-227 — one update, asynchronous.
     void compute() { check(pcl_step(h_)); }
+    // n updates with the result of n compute() calls; consecutive streaming steps share launches.
+    void compute_n(std::uint64_t n_steps) { check(pcl_step_n(h_, n_steps)); }
     // step(dt): set delta_t and run one update.
     void step(float dt) { check(pcl_step_dt(h_, dt)); }
 

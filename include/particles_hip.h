@@ -226,6 +226,16 @@ int pcl_update_sim_params(pcl_compute* h, const pcl_sim_params* params);
  * particle from the current buffer into the other one, then flip. */
 int pcl_step(pcl_compute* h);
 
+/* n_steps updates, with the same result as n_steps calls of pcl_step (bit for
+ * bit).  For callers that do not look at the state, edit the field or change
+ * parameters between those steps: while the pair term is inert, runs of
+ * consecutive steps are fused into single launches that keep the particles in
+ * registers, so n fused steps cost the memory traffic of one (up to 16 per
+ * launch; the steps that refresh the particle order stay separate).  No
+ * counterpart in the reference, which renders every frame
+ * (src/renderer.rs:221-226). */
+int pcl_step_n(pcl_compute* h, uint64_t n_steps);
+
 /* Convenience: set delta_t, then pcl_step. */
 int pcl_step_dt(pcl_compute* h, float delta_t);
 
@@ -349,7 +359,8 @@ enum {
     PCL_STEP_STREAM_COUNT   = 3, /* step_stream_kernel that also histograms the field tiles */
     PCL_STEP_STREAM_SCATTER = 4, /* step_scatter_kernel: update + refresh of the tile order */
     PCL_STEP_PAIRS_BINNED   = 5, /* sort by cut-off cell + step_pairs_binned_kernel            */
-    PCL_STEP_PAIRS_GATHERED = 6  /* step_pairs_kernel over partner records given by the caller */
+    PCL_STEP_PAIRS_GATHERED = 6, /* step_pairs_kernel over partner records given by the caller */
+    PCL_STEP_STREAM_FUSED   = 7  /* step_stream_fused_kernel: several updates in one launch      */
 };
 
 /* Per-launch timing: between begin and read every pcl_step is bracketed by a

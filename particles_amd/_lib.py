@@ -17,7 +17,7 @@ PCL_ERR_OUT_OF_RANGE = -4
 
 KERNEL_NONE, KERNEL_STREAM, KERNEL_PAIRS = 0, 1, 2
 STEP_NONE, STEP_STREAM, STEP_PAIRS, STEP_STREAM_COUNT, STEP_STREAM_SCATTER, STEP_PAIRS_BINNED = 0, 1, 2, 3, 4, 5
-STEP_PAIRS_GATHERED = 6
+STEP_PAIRS_GATHERED, STEP_STREAM_FUSED = 6, 7
 PAIRS_AUTO, PAIRS_ALL, PAIRS_BINNED = 0, 1, 2
 
 
@@ -69,6 +69,7 @@ SIGNATURES = {
     "pcl_num_cells": (_sz, [_vp]),
     "pcl_update_sim_params": (_i, [_vp, _vp]),
     "pcl_step": (_i, [_vp]),
+    "pcl_step_n": (_i, [_vp, _u64]),
     "pcl_step_dt": (_i, [_vp, _f]),
     "pcl_pack_pair_sources_device": (_i, [_vp, _vp, _sz]),
     "pcl_step_pairs_gathered": (_i, [_vp, _vp, _sz]),

@@ -161,6 +161,12 @@ class Compute:
         """One update whose pair partners are the gathered records of all ranges."""
         _lib.check(self._lib.pcl_step_pairs_gathered(self._h, C.c_void_p(int(dev_sources)), int(n_sources)))
 
+    def step_n(self, n_steps):
+        """``n_steps`` updates with the result of ``n_steps`` calls of
+        ``compute()``; consecutive streaming steps are fused into single
+        launches (the state stays in registers between them)."""
+        _lib.check(self._lib.pcl_step_n(self._h, int(n_steps)))
+
     def patch_force_grid(self, first_cell, cells):
         g = _as_cells(cells)
         _lib.check(self._lib.pcl_patch_force_grid(self._h, int(first_cell), _ptr(g), g.shape[0]))

@@ -68,6 +68,8 @@ constexpr int kAutoReorderInterval = 12;               // steps between refreshe
 constexpr size_t kAutoReorderMinFieldBytes = 64u * 1024u;        // smaller fields are staged in LDS instead
 constexpr size_t kAutoReorderMinParticles = size_t(1) << 20;
 constexpr size_t kPairBinnedMinParticles = size_t(1) << 15;  // automatic switch to the cell-binned pair kernel
+// Most steps one launch of step_stream_fused_kernel performs (the kernel is VALU-bound well before).
+constexpr uint32_t kMaxFusedSteps = 16;
 constexpr size_t kPairSmallSet = size_t(1) << 18;     // up to here the pair kernel runs one wave per block
 constexpr size_t kArrayStagger = 4096;                // see reserve_particles
 constexpr uint32_t kFoldBlocks = 64;                 // first-level blocks of the diagnostics fold
@@ -120,6 +122,8 @@ struct pcl_compute {
 
     bool force_pairs = false;
     int pair_mode = 0;                 // PCL_PAIRS_AUTO / _ALL / _BINNED
+    uint32_t fuse_request = 0;                 // pcl_step_n: how many steps the caller still wants
+    uint32_t last_advanced = 1;                // steps the last launch performed
     bool gathered_step = false;                // the step in progress takes its partners from ext_sources
     const pcl::f32x4* ext_sources = nullptr;   // caller's device memory, valid for that step only
     size_t n_ext_sources = 0;
@@ -580,6 +584,7 @@ int do_step_impl(pcl_compute* h, int* kind)
     const bool use_pairs = h->force_pairs || !inert || gathered;
     h->last_kernel = use_pairs ? PCL_KERNEL_PAIRS : PCL_KERNEL_STREAM;
     *kind = use_pairs ? PCL_STEP_PAIRS : PCL_STEP_STREAM;
+    h->last_advanced = 1;
     if (h->n == 0) {
         h->cur ^= 1;
         h->steps += 1;
@@ -589,6 +594,7 @@ int do_step_impl(pcl_compute* h, int* kind)
     PCL_REQUIRE(h->n_cells >= 1, "the force grid is empty");
     const pcl::StepUniforms U = uniforms_of(h);
     uint32_t grid = 0;
+    uint32_t advanced = 1;   // steps this launch performs
 
     bool flipped = false;   // the launch already flipped the buffers
     if (!use_pairs) {
@@ -643,6 +649,32 @@ int do_step_impl(pcl_compute* h, int* kind)
             a.hist = h->d_hist;
             const bool lds = use_lds_field(h);
             a.lds_cells = lds ? (uint32_t)h->n_cells : 0u;
+            // pcl_step_n: as many of the requested steps as fit before the next counting or
+            // scatter step go into one launch.
+            if (h->fuse_request > 1 && !count && !lds) {
+                uint64_t room = h->fuse_request;
+                if (interval > 0 && h->sorted) {
+                    const uint64_t plain_left = (uint64_t)interval - h->steps_since_sort - ((h->variant & 8u) ? 0u : 1u);
+                    room = std::min<uint64_t>(room, interval > 1 ? plain_left : 1u);
+                }
+                advanced = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(room, 1u), kMaxFusedSteps);
+            }
+            if (advanced > 1) {
+                const size_t tiles = stream_tiles(h->n);   // the fused kernel takes exactly one tile per block
+                PCL_REQUIRE(tiles <= 0x7FFFFFFFu, "too many particles for one launch");
+                grid = (uint32_t)tiles;
+                if (h->step_diag)
+                    if (int rc = reserve_partials(h, grid)) return rc;
+                if (h->step_diag)
+                    hipLaunchKernelGGL((pcl::step_stream_fused_kernel<true>), dim3(grid), dim3(pcl::kStreamThreads), 0,
+                                       h->stream, a, U, advanced);
+                else
+                    hipLaunchKernelGGL((pcl::step_stream_fused_kernel<false>), dim3(grid), dim3(pcl::kStreamThreads), 0,
+                                       h->stream, a, U, advanced);
+                PCL_HIP_TRY(hipGetLastError());
+                h->hist_valid = false;
+                *kind = PCL_STEP_STREAM_FUSED;
+            } else {
             const bool nt = (h->variant & 1u) == 0;
             int rc;
             if (h->step_diag) rc = nt ? launch_stream<true, true>(h, a, U, T, grid, lds, count) : launch_stream<true, false>(h, a, U, T, grid, lds, count);
@@ -651,6 +683,7 @@ int do_step_impl(pcl_compute* h, int* kind)
             h->hist_valid = count;
             if (count) h->hist_tiles = T;
             if (count) *kind = PCL_STEP_STREAM_COUNT;
+            }
         }
     } else if (!gathered && use_binned_pairs(h)) {
         // Cell-binned pair term: sort by cut-off cell, then sweep the 27 neighbour cells.
@@ -760,8 +793,9 @@ int do_step_impl(pcl_compute* h, int* kind)
     }
 
     if (!flipped) h->cur ^= 1;
-    h->steps += 1;
-    h->steps_since_sort += 1;
+    h->steps += advanced;
+    h->steps_since_sort += advanced;
+    h->last_advanced = advanced;
     if (h->step_diag) {
         if (int rc = launch_finalize(h, grid, h->d_diag)) return rc;
         h->diag_current = true;
@@ -1250,6 +1284,19 @@ int pcl_update_sim_params(pcl_compute* h, const pcl_sim_params* params)
 }
 
 int pcl_step(pcl_compute* h) { return do_step(h); }
+
+int pcl_step_n(pcl_compute* h, uint64_t n_steps)
+{
+    PCL_REQUIRE(h, "null handle");
+    int rc = PCL_OK;
+    while (n_steps > 0 && rc == PCL_OK) {
+        h->fuse_request = (uint32_t)std::min<uint64_t>(n_steps, 0xFFFFFFFFull);
+        rc = do_step(h);
+        n_steps -= std::min<uint64_t>(n_steps, h->last_advanced);
+    }
+    h->fuse_request = 0;
+    return rc;
+}
 
 int pcl_step_dt(pcl_compute* h, float delta_t)
 {

@@ -423,6 +423,71 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_kernel(StreamArgs 
     if (DIAG) block_reduce_store<kStreamThreads>(acc, a.partials + blockIdx.x);
 }
 
+// Several consecutive updates of every particle in one pass over the arrays:
+// the state stays in registers between the sub-steps, so HBM traffic is that of
+// ONE step (49 B per particle) however many are fused; each sub-step fetches
+// its own field cell.  The arithmetic of every sub-step is that of
+// step_stream_kernel, so k fused steps equal k single steps bit for bit.  Only
+// for callers that do not need the intermediate states (no rendering, no field
+// edit, no parameter change between the fused steps).
+template <bool DIAG>
+__global__ __launch_bounds__(kStreamThreads) void step_stream_fused_kernel(StreamArgs a, StepUniforms U,
+                                                                          uint32_t sub_steps)
+{
+    DiagAcc acc;
+    if (DIAG) acc.init();
+    const unsigned long long n_groups = a.n / 4ull;
+    const unsigned long long g = (unsigned long long)blockIdx.x * kStreamThreads + threadIdx.x;
+    if (g < n_groups) {
+        f32x4 X = load4<true>(a.src[0], g);
+        f32x4 Y = load4<true>(a.src[1], g);
+        f32x4 Z = load4<true>(a.src[2], g);
+        f32x4 VX = load4<true>(a.src[3], g);
+        f32x4 VY = load4<true>(a.src[4], g);
+        f32x4 VZ = load4<true>(a.src[5], g);
+        const uint32_t t4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.ty) + g);
+        float m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = mass_of(U, (t4 >> (8 * k)) & 0xFFu);
+        for (uint32_t s = 0; s < sub_steps; ++s) {
+            f32x4 F[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) F[k] = a.field[cell_index(U, X[k], Y[k], Z[k])];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float x = X[k], y = Y[k], z = Z[k], vx = VX[k], vy = VY[k], vz = VZ[k];
+                integrate(U, F[k].x, F[k].y, F[k].z, m[k], 0.0f, 0.0f, 0.0f, x, y, z, vx, vy, vz);
+                X[k] = x; Y[k] = y; Z[k] = z; VX[k] = vx; VY[k] = vy; VZ[k] = vz;
+            }
+        }
+        if (DIAG) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc.add(m[k], X[k], Y[k], Z[k], VX[k], VY[k], VZ[k]);
+        }
+        store4<true>(a.dst[0], g, X);
+        store4<true>(a.dst[1], g, Y);
+        store4<true>(a.dst[2], g, Z);
+        store4<true>(a.dst[3], g, VX);
+        store4<true>(a.dst[4], g, VY);
+        store4<true>(a.dst[5], g, VZ);
+    }
+    // Up to 3 particles past the last full group: block 0, lanes 0..2.
+    const unsigned long long tail = n_groups * 4ull + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 3 && tail < a.n) {
+        float x = a.src[0][tail], y = a.src[1][tail], z = a.src[2][tail];
+        float vx = a.src[3][tail], vy = a.src[4][tail], vz = a.src[5][tail];
+        const float m = mass_of(U, a.ty[tail]);
+        for (uint32_t s = 0; s < sub_steps; ++s) {
+            const f32x4 f = a.field[cell_index(U, x, y, z)];
+            integrate(U, f.x, f.y, f.z, m, 0.0f, 0.0f, 0.0f, x, y, z, vx, vy, vz);
+        }
+        a.dst[0][tail] = x; a.dst[1][tail] = y; a.dst[2][tail] = z;
+        a.dst[3][tail] = vx; a.dst[4][tail] = vy; a.dst[5][tail] = vz;
+        if (DIAG) acc.add(m, x, y, z, vx, vy, vz);
+    }
+    if (DIAG) block_reduce_store<kStreamThreads>(acc, a.partials + blockIdx.x);
+}
+
 // -------------------------------------------------------- general kernel K2
 
 // Parameter block as the reference lays it out (912 bytes): wgsl:17-28.

@@ -262,6 +262,17 @@ class ShardedCompute:
         if self._diag_enabled:
             self._start_diag_allreduce()
 
+    def compute_n(self, n_steps):
+        """``n_steps`` updates of the local range (fused launches where the
+        path allows); step diagnostics describe the final state."""
+        if self._pair_active and self._collectives and self.n_total > 0:
+            for _ in range(int(n_steps)):
+                self._pair_step()
+        else:
+            self.local.step_n(n_steps)
+        if self._diag_enabled:
+            self._start_diag_allreduce()
+
     def step(self, dt=None):
         self._advance(dt)
         if self._diag_enabled:

@@ -57,6 +57,10 @@ class OracleCompute:
             self.sp.delta_t = dt
         self.compute()
 
+    def step_n(self, n_steps):
+        for _ in range(int(n_steps)):
+            self.compute()
+
     def pack_pair_sources(self, capacity_records):
         """(x, y, z, type bits) per particle, padded with type 0xFFFFFFFF records."""
         rec = np.zeros((capacity_records, 4), dtype=np.float32)

@@ -470,3 +470,43 @@ def test_binned_pairs_then_stream_then_exact(oracle):
         c.set_pair_mode(1)
         c.compute()
         assert_particles_bit_equal(c.read_particles(), oracle.run(sp, mid2, g, 1), "exact pairs after stream")
+
+
+@pytest.mark.parametrize("n,interval,steps", [(1003, 0, 7), (5000, 5, 23), (70001, 12, 40), (4, 0, 2), (3, 0, 5), (50000, 3, 17)])
+def test_fused_steps_equal_single_steps(oracle, n, interval, steps):
+    """pcl_step_n: runs of streaming steps fused into one launch (state kept
+    in registers) give the bits of the same number of single steps, across the
+    counting and scatter steps of the tile order."""
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    sp.force_grid_dimensions = (96, 80, 1)
+    g = scene_swirl_field(96, 80, 1, 10.0, seed=8)
+    p = oracle.synth_particles(n, seed=n, pos_extent=20.0, vel_extent=10.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        c.set_reorder_interval(interval)
+        c.enable_step_diagnostics(True)
+        c.step_timing_begin(steps)
+        c.step_n(steps)
+        ms, kinds = c.step_timing_read()
+        got = c.read_particles()
+        d = c.diagnostics()
+        assert c.step_count == steps
+    want = oracle.run(sp, p, g, steps, mode=oracle.MODE_SKIP_INERT)
+    assert_particles_bit_equal(got, want, f"{steps} steps through pcl_step_n")
+    wd = oracle.diagnostics(sp, want)
+    assert d["count"] == n and abs(d["kinetic_energy"] - wd["kinetic_energy"]) <= 1e-12 * max(1.0, wd["kinetic_energy"])
+    if interval == 0 or (n >= 4096 and interval >= 5):   # interval 3 leaves one plain step per cycle: nothing to fuse
+        assert (kinds == pa.STEP_STREAM_FUSED).any() and len(kinds) < steps   # fewer launches than steps
+
+
+def test_step_n_with_pair_term_falls_back_to_single_steps(oracle):
+    sp = pair_params(0.0)
+    g = sp.new_force_grid_centered().get_force_vectors()
+    p = oracle.synth_particles(500, seed=3, pos_extent=6.0, vel_extent=4.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        c.step_n(3)
+        assert c.step_count == 3 and c.last_step_kernel == pa.KERNEL_PAIRS
+        assert_particles_bit_equal(c.read_particles(), oracle.run(sp, p, g, 3), "pair steps through pcl_step_n")
