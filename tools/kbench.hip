@@ -107,24 +107,6 @@ __global__ __launch_bounds__(CH / 4) void copy_chunked_kernel(const char* __rest
     for (int k = 0; k < 6; ++k) store4<NT>(reinterpret_cast<float*>(db + (size_t)k * CH * 4), threadIdx.x, v[k]);
 }
 
-// Structural variants of the chunked copy: TYPE 0 = no type stream, 1 = type loaded last, 2 = type loaded first.
-template <int TYPE, int CH, int K>
-__global__ __launch_bounds__(CH / 4) void copy_chunked2_kernel(const char* __restrict__ s, char* __restrict__ d)
-{
-    const size_t chunk = (size_t)CH * (4 * K + 1);
-    const char* sb = s + (size_t)blockIdx.x * chunk;
-    char* db = d + (size_t)blockIdx.x * chunk;
-    f32x4 v[K];
-    uint32_t t = 0;
-    if (TYPE == 2) t = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sb + (size_t)CH * 4 * K) + threadIdx.x);
-#pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = load4<true>(reinterpret_cast<const float*>(sb + (size_t)k * CH * 4), threadIdx.x);
-    if (TYPE == 1) t = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sb + (size_t)CH * 4 * K) + threadIdx.x);
-    if (TYPE) v[0].x += __uint_as_float(t & 1u);
-#pragma unroll
-    for (int k = 0; k < K; ++k) store4<true>(reinterpret_cast<float*>(db + (size_t)k * CH * 4), threadIdx.x, v[k]);
-}
-
 // Plain float4 copy a -> b
 template <bool NT>
 __global__ __launch_bounds__(256) void copy1_kernel(const f32x4* __restrict__ s, f32x4* __restrict__ d, unsigned long long n4)
@@ -382,27 +364,6 @@ int main(int argc, char** argv)
             });
             printf("contiguous nt copy %5zu MiB -> %5zu MiB: %8.4f ms %8.1f GB/s\n", mib, mib, ms, 2.0 * mib * 1048576.0 / ms / 1e6);
         }
-    }
-    if (set == 6) {
-        char* A = slab;
-        char* B = slab + (size_t)6 * arr_bytes;
-#define RUN2(TYPE, CH, K)                                                                                         \
-        {                                                                                                         \
-            const size_t chunk_bytes = (size_t)CH * (4 * K + 1);                                                  \
-            const size_t half_bytes = (size_t)6 * arr_bytes;                                                      \
-            const unsigned g = (unsigned)std::min<size_t>(c.n * 6 / K / CH, half_bytes / chunk_bytes);            \
-            if ((size_t)g * chunk_bytes > half_bytes) { printf("bounds\n"); return 1; }                           \
-            float ms = time_ms(c, [&](StreamArgs& a) {                                                            \
-                const bool f = &a == &c.fwd;                                                                      \
-                hipLaunchKernelGGL((copy_chunked2_kernel<TYPE, CH, K>), dim3(g), dim3(CH / 4), 0, 0, f ? A : B, f ? B : A); \
-            });                                                                                                   \
-            const double bytes = (double)g * CH * (8.0 * K + (TYPE ? 1 : 0));                                     \
-            printf("chunked type=%d CH=%d K=%d: %8.4f ms %8.1f GB/s\n", TYPE, CH, K, ms, bytes / ms / 1e6);         \
-        }
-        RUN2(0, 2048, 6) RUN2(1, 2048, 6) RUN2(2, 2048, 6)
-        RUN2(0, 256, 6) RUN2(0, 1024, 6) RUN2(0, 4096, 6)
-        RUN2(0, 2048, 1) RUN2(0, 2048, 2) RUN2(0, 2048, 3) RUN2(0, 2048, 4) RUN2(0, 2048, 8) RUN2(0, 2048, 12)
-        RUN2(0, 1024, 1) RUN2(0, 1024, 2) RUN2(0, 1024, 3)
     }
     return 0;
 }
