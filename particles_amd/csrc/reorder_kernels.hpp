@@ -123,19 +123,6 @@ struct ScatterLds {
     }
 };
 
-// Barrier for hand-offs that go through LDS only.  __syncthreads() also waits
-// for the wave's outstanding global loads and stores (vmcnt(0)); in the scatter
-// kernels that would drain every array's scattered stores before the next
-// array may be staged (measured: two thirds of the wave cycles parked).  Here
-// only LDS traffic is ordered; nothing in these kernels hands global data from
-// one wave of the block to another.
-__device__ __forceinline__ void lds_barrier()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
 // After every thread has added its particles to slot[] (lds_rank_add): turn the
 // per-bin counts into local start positions, reserve each non-empty bin's run of
 // global slots with one atomic add, and leave in slot[b] the offset that maps a

@@ -130,6 +130,18 @@ __device__ __forceinline__ void integrate(const StepUniforms& U, float fx, float
     z = wrap_symmetrically(z, U.radius, U.two_radius);
 }
 
+// Barrier for hand-offs that go through LDS only.  __syncthreads() also waits
+// for the wave's outstanding global loads and stores (vmcnt(0)); where the
+// hand-off goes through LDS only that wait is wasted: a block would drain its
+// stores before it may reduce its diagnostics or stage the next array of a
+// scatter.  Here only LDS traffic is ordered.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // ------------------------------------------------------- diagnostics pieces
 
 struct DiagAcc {
@@ -194,7 +206,7 @@ __device__ __forceinline__ void block_reduce_store(DiagAcc acc, DiagPartial* out
         p.pad[0] = p.pad[1] = 0.0f;
         wave_part[wave] = p;
     }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x == 0) {
         DiagPartial p = wave_part[0];
         for (int w = 1; w < THREADS / 64; ++w) {
