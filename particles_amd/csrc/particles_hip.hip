@@ -1024,15 +1024,16 @@ int pcl_create(const pcl_particle* particles, size_t n, const float (*force_grid
 int pcl_upload_particles(pcl_compute* h, const pcl_particle* particles, size_t n)
 {
     if (int rc = bind(h)) return rc;
-    h->sorted = false;          // a fresh set is in caller order
-    h->slot_of_valid = false;
-    h->hist_valid = false;
+    // a rejected call leaves the handle as it was
     PCL_REQUIRE(n == 0 || particles != nullptr, "pcl_upload_particles: particles is null");
     for (size_t i = 0; i < n; ++i)
         if (particles[i].ty >= PCL_NUM_TYPES)
             return fail(PCL_ERR_INVALID, "pcl_upload_particles: particle " + std::to_string(i) +
                                              " has type " + std::to_string(particles[i].ty) + " (must be < 5)");
     if (int rc = reserve_particles(h, n)) return rc;
+    h->sorted = false;          // a fresh set is in caller order
+    h->slot_of_valid = false;
+    h->hist_valid = false;
     h->n = n;
     h->diag_current = false;
     if (n == 0) return PCL_OK;
@@ -1062,9 +1063,6 @@ int pcl_upload_particles_soa(pcl_compute* h, size_t n, const float* x, const flo
                              const float* vx, const float* vy, const float* vz, const uint8_t* ty)
 {
     if (int rc = bind(h)) return rc;
-    h->sorted = false;          // a fresh set is in caller order
-    h->slot_of_valid = false;
-    h->hist_valid = false;
     const float* src[6] = {x, y, z, vx, vy, vz};
     if (n) {
         for (int a = 0; a < 6; ++a) PCL_REQUIRE(src[a] != nullptr, "pcl_upload_particles_soa: null array");
@@ -1075,6 +1073,9 @@ int pcl_upload_particles_soa(pcl_compute* h, size_t n, const float* x, const flo
                                                  " has type " + std::to_string(ty[i]) + " (must be < 5)");
     }
     if (int rc = reserve_particles(h, n)) return rc;
+    h->sorted = false;          // a fresh set is in caller order
+    h->slot_of_valid = false;
+    h->hist_valid = false;
     h->n = n;
     h->diag_current = false;
     if (n == 0) return PCL_OK;

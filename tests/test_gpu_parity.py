@@ -510,3 +510,23 @@ def test_step_n_with_pair_term_falls_back_to_single_steps(oracle):
         c.step_n(3)
         assert c.step_count == 3 and c.last_step_kernel == pa.KERNEL_PAIRS
         assert_particles_bit_equal(c.read_particles(), oracle.run(sp, p, g, 3), "pair steps through pcl_step_n")
+
+
+def test_rejected_upload_leaves_a_tile_ordered_set_intact(oracle):
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = (96, 80, 1)
+    g = scene_swirl_field(96, 80, 1, 10.0, seed=8)
+    p = oracle.synth_particles(6000, seed=1, pos_extent=20.0, vel_extent=10.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        c.set_reorder_interval(2)
+        for _ in range(3):
+            c.compute()
+        assert c.reorder_count >= 1          # slots are no longer in caller order
+        bad = p.copy().view(pa.PARTICLE_DTYPE)
+        bad["ty"][17] = 9
+        with pytest.raises(pa.PclError):
+            c.upload_particles(bad)
+        want = oracle.run(sp, p, g, 3, mode=oracle.MODE_SKIP_INERT)
+        assert_particles_bit_equal(c.read_particles(), want, "state after a rejected upload")
