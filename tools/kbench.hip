@@ -107,6 +107,20 @@ __global__ __launch_bounds__(CH / 4) void copy_chunked_kernel(const char* __rest
     for (int k = 0; k < 6; ++k) store4<NT>(reinterpret_cast<float*>(db + (size_t)k * CH * 4), threadIdx.x, v[k]);
 }
 
+// Copy of K of the six arrays (float4 per lane per array): how the streaming rate depends on
+// the number of loads and stores one lane issues.
+template <int K, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void copyk_kernel(StreamArgs a)
+{
+    const unsigned long long g = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= a.n / 4ull) return;   // every array holds a.n floats
+    f32x4 v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = load4<true>(a.src[k], g);
+#pragma unroll
+    for (int k = 0; k < K; ++k) store4<true>(a.dst[k], g, v[k]);
+}
+
 // Plain float4 copy a -> b
 template <bool NT>
 __global__ __launch_bounds__(256) void copy1_kernel(const f32x4* __restrict__ s, f32x4* __restrict__ d, unsigned long long n4)
@@ -364,6 +378,20 @@ int main(int argc, char** argv)
             });
             printf("contiguous nt copy %5zu MiB -> %5zu MiB: %8.4f ms %8.1f GB/s\n", mib, mib, ms, 2.0 * mib * 1048576.0 / ms / 1e6);
         }
+    }
+    if (set == 7) {
+#define RUNK(K, BLOCK)                                                                                            \
+        {                                                                                                         \
+            const unsigned grid = (unsigned)((c.n / 4 + BLOCK - 1) / BLOCK);                                      \
+            float ms = time_ms(c, [&](StreamArgs& a) {                                                            \
+                hipLaunchKernelGGL((copyk_kernel<K, BLOCK>), dim3(grid), dim3(BLOCK), 0, 0, a);                   \
+            });                                                                                                   \
+            printf("copy of %d arrays, block %4d: %8.4f ms %8.1f GB/s\n", K, BLOCK, ms, c.n * 8.0 * K / ms / 1e6); \
+            fflush(stdout);                                                                                       \
+        }
+        RUNK(1, 256) RUNK(2, 256) RUNK(3, 256) RUNK(4, 256) RUNK(6, 256)
+        RUNK(1, 512) RUNK(2, 512) RUNK(3, 512) RUNK(6, 512)
+        RUNK(1, 1024) RUNK(3, 1024) RUNK(6, 1024)
     }
     return 0;
 }
