@@ -76,3 +76,47 @@ def test_pair_path_random_parameters(oracle, seed):
             if f == "pos":
                 d = np.minimum(d, np.abs(two_r - d))
             assert np.all(d <= 1e-5 * np.maximum(np.abs(a), np.abs(b)) + 1e-6), f"pairs seed {seed} {f}"
+
+
+@pytest.mark.parametrize("case", ["denormal_field", "denormal_velocity", "tiny_dt", "tiny_radius", "huge_radius",
+                                  "zero_speed_cap", "negative_zero_velocity", "extreme_masses"])
+def test_stream_path_extreme_but_finite_values(oracle, case):
+    """Denormals, signed zeros and extreme magnitudes: the device keeps fp32
+    denormals and IEEE division, so these match the CPU bit for bit too."""
+    rng = np.random.default_rng(77)
+    sp = pa.SimParams()
+    sp.delta_t = np.float32(1.0 / 60.0)
+    sp.force_grid_dimensions = (8, 5, 3)
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    g = np.ones((120, 4), dtype=np.float32)
+    g[:, :3] = rng.uniform(-3, 3, size=(120, 3)).astype(np.float32)
+    vel_extent = 10.0
+    if case == "denormal_field":
+        g[:, :3] = (rng.uniform(-1, 1, size=(120, 3)) * 1e-39).astype(np.float32)
+        vel_extent = 0.0
+    elif case == "denormal_velocity":
+        vel_extent = 1e-41
+        g[:, :3] = 0.0
+    elif case == "tiny_dt":
+        sp.delta_t = np.float32(1e-30)
+    elif case == "tiny_radius":
+        sp.bounding_volume_radius = np.float32(1e-3)
+    elif case == "huge_radius":
+        sp.bounding_volume_radius = np.float32(1e6)
+    elif case == "zero_speed_cap":
+        sp.max_velocity = np.float32(0.0)
+    elif case == "extreme_masses":
+        sp.masses = (1e-6, 1e6, 1e-3, 1e3, 1.0)
+    r = float(sp.bounding_volume_radius)
+    p = oracle.synth_particles(3001, seed=5, pos_extent=2.0 * r, vel_extent=vel_extent)
+    if case == "negative_zero_velocity":
+        p["vel"][:, :3] = np.float32(-0.0)
+        g[::2, :3] = 0.0                      # half the cells exert no force: -0 must survive the update
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        for _ in range(4):
+            c.compute()
+        got = c.read_particles()
+    want = oracle.run(sp, p, g, 4, mode=oracle.MODE_SKIP_INERT)
+    assert np.isfinite(want["pos"]).all() and np.isfinite(want["vel"]).all()
+    assert_particles_bit_equal(got, want, case)
