@@ -368,7 +368,7 @@ uint32_t floor_log2(uint32_t v)
 // Tiles of at most 256 cells (4 KiB of field), z extent first because z is the
 // fastest-varying cell coordinate; tiles grow until there are at most
 // kMaxReorderBins of them.
-pcl::TileMap make_tile_map(const pcl_sim_params& p, int interval, uint32_t log2_tile_cells = 8)
+pcl::TileMap make_tile_map(const pcl_sim_params& p, int interval, uint32_t log2_tile_cells = 8, float aim = 0.5f)
 {
     const uint32_t d[3] = {std::max(1u, p.force_grid_dimensions[0]), std::max(1u, p.force_grid_dimensions[1]),
                            std::max(1u, p.force_grid_dimensions[2])};
@@ -393,7 +393,7 @@ pcl::TileMap make_tile_map(const pcl_sim_params& p, int interval, uint32_t log2_
     const float side = p.bounding_volume_radius * 2.0f;
     for (int a = 0; a < 3; ++a) T.inv_cell[a] = (side > 0.0f && std::isfinite(side)) ? (float)d[a] / side : 0.0f;
     // aim the order at the middle of the refresh interval
-    T.lookahead = interval > 1 ? p.delta_t * (0.5f * (float)interval) : 0.0f;
+    T.lookahead = interval > 1 ? p.delta_t * (aim * (float)interval) : 0.0f;
     return T;
 }
 
@@ -402,6 +402,14 @@ uint32_t tile_log2(const pcl_compute* h)
 {
     const uint32_t v = (h->variant >> 4) & 0xFu;
     return v ? v : 8u;
+}
+
+// Which point of the refresh interval the order is aimed at, as a fraction of
+// the interval (tuning: variant bits 12..15 give it in tenths).
+float tile_aim(const pcl_compute* h)
+{
+    const uint32_t v = (h->variant >> 12) & 0xFu;
+    return v ? 0.1f * (float)v : 0.5f;
 }
 
 // How often the tile order is refreshed: the caller's setting, or by default
@@ -490,7 +498,7 @@ int do_reorder(pcl_compute* h)
 {
     if (h->n == 0) return PCL_OK;
     if (int rc = reserve_reorder(h)) return rc;
-    const pcl::TileMap T = make_tile_map(h->params, effective_reorder_interval(h), tile_log2(h));
+    const pcl::TileMap T = make_tile_map(h->params, effective_reorder_interval(h), tile_log2(h), tile_aim(h));
     const pcl::StepUniforms U = uniforms_of(h);
     if (int rc = reorder_count(h, U, T)) return rc;
     pcl::ReorderArgs a;
@@ -601,7 +609,7 @@ int do_step_impl(pcl_compute* h, int* kind)
         const int interval = effective_reorder_interval(h);
         const bool sort_now = interval > 0 && (!h->sorted || h->steps_since_sort >= (uint64_t)interval);
         // A pending histogram fixes the key function (delta_t, hence the lookahead, may change per frame).
-        const pcl::TileMap T = (sort_now && h->hist_valid) ? h->hist_tiles : make_tile_map(h->params, interval, tile_log2(h));
+        const pcl::TileMap T = (sort_now && h->hist_valid) ? h->hist_tiles : make_tile_map(h->params, interval, tile_log2(h), tile_aim(h));
         if (sort_now) {
             // Update and scatter into tile order in one pass.
             if (int rc = reserve_reorder(h)) return rc;
