@@ -183,12 +183,18 @@ __device__ __forceinline__ void scatter_load(const ReorderArgs& a, unsigned long
                                              bool full, bool is_tail, f32x4 V[6], uint32_t& t4, uint32_t orig[4])
 {
     if (full) {
+        // this block's tile through per-tile buffer resources (see tile_rsrc)
+        const unsigned long long n_groups = a.n / 4ull;
+        const unsigned long long g0 = (unsigned long long)blockIdx.x * kStreamThreads;   // g = g0 + threadIdx.x
+        const uint32_t groups = (uint32_t)(n_groups - g0 < (unsigned long long)kStreamThreads ? n_groups - g0 : kStreamThreads);
+        const uint32_t lane16 = threadIdx.x * 16u;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) V[c] = load4<true>(a.src[c], g);
-        t4 = reinterpret_cast<const uint32_t*>(a.src_ty)[g];
+        for (int c = 0; c < 6; ++c) V[c] = tile_load4(tile_rsrc(a.src[c] + g0 * 4ull, groups * 16u), lane16);
+        t4 = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc(a.src_ty + g0 * 4ull, groups * 4u), (int)(threadIdx.x * 4u), 0, 2);
         if (a.src_orig) {
-            const u32x4 o = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.src_orig) + g);
-            orig[0] = o.x; orig[1] = o.y; orig[2] = o.z; orig[3] = o.w;
+            const f32x4 o = tile_load4(tile_rsrc(a.src_orig + g0 * 4ull, groups * 16u), lane16);
+            orig[0] = __float_as_uint(o.x); orig[1] = __float_as_uint(o.y);
+            orig[2] = __float_as_uint(o.z); orig[3] = __float_as_uint(o.w);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) orig[k] = (uint32_t)(g * 4ull + k);

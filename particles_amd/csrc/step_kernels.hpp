@@ -338,6 +338,28 @@ __device__ __forceinline__ void store4(float* base, unsigned long long group, f3
     else *p = v;
 }
 
+// Non-temporal access to one block's tile of a particle array through a buffer
+// resource whose base is the tile (wave-uniform, in SGPRs) and whose extent is
+// the tile's valid bytes: the lane supplies a 32-bit offset only, so no 64-bit
+// address arithmetic runs per lane, and the array may be of any size.
+// (0x00020000: raw buffer, 32-bit data format; aux 2 = nt.)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* tile_base, uint32_t valid_bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(tile_base), 0, valid_bytes, 0x00020000);
+}
+
+__device__ __forceinline__ f32x4 tile_load4(__amdgpu_buffer_rsrc_t r, uint32_t lane_byte)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_byte, 0, 2));
+}
+
+__device__ __forceinline__ void tile_store4(__amdgpu_buffer_rsrc_t r, uint32_t lane_byte, f32x4 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, (int)lane_byte, 0, 2);
+}
+
 // Pair term provably zero (every polynomial coefficient +-0, or no distance
 // can pass both cut-offs): wgsl:115-144 contributes exactly +0, so the update
 // is a pure stream: 24 B state + 1 B type in, 24 B out per particle, plus one
@@ -380,14 +402,29 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_kernel(StreamArgs 
     for (unsigned long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const unsigned long long g = t * kStreamThreads + threadIdx.x;
         if (g >= n_groups) break;
-        f32x4 X = load4<NT>(a.src[0], g);
-        f32x4 Y = load4<NT>(a.src[1], g);
-        f32x4 Z = load4<NT>(a.src[2], g);
-        f32x4 VX = load4<NT>(a.src[3], g);
-        f32x4 VY = load4<NT>(a.src[4], g);
-        f32x4 VZ = load4<NT>(a.src[5], g);
-        const uint32_t t4 = NT ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.ty) + g)
-                               : reinterpret_cast<const uint32_t*>(a.ty)[g];
+        // the tile's groups, and this lane's byte offset inside the tile
+        const unsigned long long g0 = t * kStreamThreads;
+        const uint32_t groups = (uint32_t)(n_groups - g0 < (unsigned long long)kStreamThreads ? n_groups - g0 : kStreamThreads);
+        const uint32_t lane16 = threadIdx.x * 16u;
+        f32x4 X, Y, Z, VX, VY, VZ;
+        uint32_t t4;
+        if (NT) {
+            X = tile_load4(tile_rsrc(a.src[0] + g0 * 4ull, groups * 16u), lane16);
+            Y = tile_load4(tile_rsrc(a.src[1] + g0 * 4ull, groups * 16u), lane16);
+            Z = tile_load4(tile_rsrc(a.src[2] + g0 * 4ull, groups * 16u), lane16);
+            VX = tile_load4(tile_rsrc(a.src[3] + g0 * 4ull, groups * 16u), lane16);
+            VY = tile_load4(tile_rsrc(a.src[4] + g0 * 4ull, groups * 16u), lane16);
+            VZ = tile_load4(tile_rsrc(a.src[5] + g0 * 4ull, groups * 16u), lane16);
+            t4 = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc(a.ty + g0 * 4ull, groups * 4u), (int)(threadIdx.x * 4u), 0, 2);
+        } else {
+            X = load4<false>(a.src[0], g);
+            Y = load4<false>(a.src[1], g);
+            Z = load4<false>(a.src[2], g);
+            VX = load4<false>(a.src[3], g);
+            VY = load4<false>(a.src[4], g);
+            VZ = load4<false>(a.src[5], g);
+            t4 = reinterpret_cast<const uint32_t*>(a.ty)[g];
+        }
 
         f32x4 F[4];
 #pragma unroll
@@ -403,12 +440,21 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_kernel(StreamArgs 
             if (COUNT) lds_rank_add(lds_hist, tile_key(U, T, x, y, z, vx, vy, vz), true);
         }
 
-        store4<NT>(a.dst[0], g, X);
-        store4<NT>(a.dst[1], g, Y);
-        store4<NT>(a.dst[2], g, Z);
-        store4<NT>(a.dst[3], g, VX);
-        store4<NT>(a.dst[4], g, VY);
-        store4<NT>(a.dst[5], g, VZ);
+        if (NT) {
+            tile_store4(tile_rsrc(a.dst[0] + g0 * 4ull, groups * 16u), lane16, X);
+            tile_store4(tile_rsrc(a.dst[1] + g0 * 4ull, groups * 16u), lane16, Y);
+            tile_store4(tile_rsrc(a.dst[2] + g0 * 4ull, groups * 16u), lane16, Z);
+            tile_store4(tile_rsrc(a.dst[3] + g0 * 4ull, groups * 16u), lane16, VX);
+            tile_store4(tile_rsrc(a.dst[4] + g0 * 4ull, groups * 16u), lane16, VY);
+            tile_store4(tile_rsrc(a.dst[5] + g0 * 4ull, groups * 16u), lane16, VZ);
+        } else {
+            store4<false>(a.dst[0], g, X);
+            store4<false>(a.dst[1], g, Y);
+            store4<false>(a.dst[2], g, Z);
+            store4<false>(a.dst[3], g, VX);
+            store4<false>(a.dst[4], g, VY);
+            store4<false>(a.dst[5], g, VZ);
+        }
     }
 
     // Up to 3 particles past the last full group: block 0, lanes 0..2.
@@ -451,13 +497,16 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_fused_kernel(Strea
     const unsigned long long n_groups = a.n / 4ull;
     const unsigned long long g = (unsigned long long)blockIdx.x * kStreamThreads + threadIdx.x;
     if (g < n_groups) {
-        f32x4 X = load4<true>(a.src[0], g);
-        f32x4 Y = load4<true>(a.src[1], g);
-        f32x4 Z = load4<true>(a.src[2], g);
-        f32x4 VX = load4<true>(a.src[3], g);
-        f32x4 VY = load4<true>(a.src[4], g);
-        f32x4 VZ = load4<true>(a.src[5], g);
-        const uint32_t t4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.ty) + g);
+        const unsigned long long g0 = (unsigned long long)blockIdx.x * kStreamThreads;
+        const uint32_t groups = (uint32_t)(n_groups - g0 < (unsigned long long)kStreamThreads ? n_groups - g0 : kStreamThreads);
+        const uint32_t lane16 = threadIdx.x * 16u;
+        f32x4 X = tile_load4(tile_rsrc(a.src[0] + g0 * 4ull, groups * 16u), lane16);
+        f32x4 Y = tile_load4(tile_rsrc(a.src[1] + g0 * 4ull, groups * 16u), lane16);
+        f32x4 Z = tile_load4(tile_rsrc(a.src[2] + g0 * 4ull, groups * 16u), lane16);
+        f32x4 VX = tile_load4(tile_rsrc(a.src[3] + g0 * 4ull, groups * 16u), lane16);
+        f32x4 VY = tile_load4(tile_rsrc(a.src[4] + g0 * 4ull, groups * 16u), lane16);
+        f32x4 VZ = tile_load4(tile_rsrc(a.src[5] + g0 * 4ull, groups * 16u), lane16);
+        const uint32_t t4 = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc(a.ty + g0 * 4ull, groups * 4u), (int)(threadIdx.x * 4u), 0, 2);
         float m[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) m[k] = mass_of(U, (t4 >> (8 * k)) & 0xFFu);
@@ -476,12 +525,12 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_fused_kernel(Strea
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc.add(m[k], X[k], Y[k], Z[k], VX[k], VY[k], VZ[k]);
         }
-        store4<true>(a.dst[0], g, X);
-        store4<true>(a.dst[1], g, Y);
-        store4<true>(a.dst[2], g, Z);
-        store4<true>(a.dst[3], g, VX);
-        store4<true>(a.dst[4], g, VY);
-        store4<true>(a.dst[5], g, VZ);
+        tile_store4(tile_rsrc(a.dst[0] + g0 * 4ull, groups * 16u), lane16, X);
+        tile_store4(tile_rsrc(a.dst[1] + g0 * 4ull, groups * 16u), lane16, Y);
+        tile_store4(tile_rsrc(a.dst[2] + g0 * 4ull, groups * 16u), lane16, Z);
+        tile_store4(tile_rsrc(a.dst[3] + g0 * 4ull, groups * 16u), lane16, VX);
+        tile_store4(tile_rsrc(a.dst[4] + g0 * 4ull, groups * 16u), lane16, VY);
+        tile_store4(tile_rsrc(a.dst[5] + g0 * 4ull, groups * 16u), lane16, VZ);
     }
     // Up to 3 particles past the last full group: block 0, lanes 0..2.
     const unsigned long long tail = n_groups * 4ull + threadIdx.x;

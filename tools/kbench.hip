@@ -15,9 +15,22 @@ using namespace pcl;
 
 // G = float4 groups per lane per array (particles per lane = 4*G)
 // GPOL: cache-policy bits of the field fetch (buffer_load aux: 1 = sc0, 2 = nt, 16 = sc1); -1 = plain global_load
-template <int G, bool NT_LD, bool NT_ST, bool PERSIST, bool GATHER, int BLOCK, int GPOL = -1, bool XCD = false>
+// SPOL: the same bits for the six particle-array loads (-1 = the library's non-temporal global_load)
+template <int G, bool NT_LD, bool NT_ST, bool PERSIST, bool GATHER, int BLOCK, int GPOL = -1, bool XCD = false, int SPOL = -1>
 __global__ __launch_bounds__(BLOCK) void variant_kernel(StreamArgs a, StepUniforms U)
 {
+    __amdgpu_buffer_rsrc_t srsrc[6];
+    if (SPOL >= 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            srsrc[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src[k]), 0, (unsigned)(a.n * 4ull), 0x00020000);
+    }
+    auto sload = [&](int k, unsigned long long g) -> f32x4 {
+        if (SPOL < 0) return load4<NT_LD>(a.src[k], g);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(srsrc[k], (int)(unsigned)(g * 16ull), 0, SPOL < 0 ? 0 : SPOL);
+        return __builtin_bit_cast(f32x4, raw);
+    };
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<f32x4*>(a.field), 0, (U.last_cell + 1u) * 16u, 0x00020000);
     const unsigned long long n_groups = a.n / 4ull;  // n is a multiple of 4*G*BLOCK here
@@ -31,12 +44,12 @@ __global__ __launch_bounds__(BLOCK) void variant_kernel(StreamArgs a, StepUnifor
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             const unsigned long long g = t * tile + (unsigned long long)j * BLOCK + threadIdx.x;
-            X[j] = load4<NT_LD>(a.src[0], g);
-            Y[j] = load4<NT_LD>(a.src[1], g);
-            Z[j] = load4<NT_LD>(a.src[2], g);
-            VX[j] = load4<NT_LD>(a.src[3], g);
-            VY[j] = load4<NT_LD>(a.src[4], g);
-            VZ[j] = load4<NT_LD>(a.src[5], g);
+            X[j] = sload(0, g);
+            Y[j] = sload(1, g);
+            Z[j] = sload(2, g);
+            VX[j] = sload(3, g);
+            VY[j] = sload(4, g);
+            VZ[j] = sload(5, g);
             T[j] = NT_LD ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.ty) + g)
                          : reinterpret_cast<const uint32_t*>(a.ty)[g];
         }
@@ -319,6 +332,39 @@ int main(int argc, char** argv)
             run_variant<1, true, true, false, false, 256>(c, "  step");
             run_variant<1, true, true, false, true, 512>(c, "  step");
         }
+    }
+    if (set == 8) {
+        // sorted particles (16x16-cell tiles), block 512: cache-policy bits of the particle-array loads
+        const unsigned tile_cells = 16;
+        auto run_spol = [&](auto kernel, const char* name) {
+            hipLaunchKernelGGL(generate_sorted_kernel, dim3(4096), dim3(256), 0, 0, c.s0, c.ty, c.n, side, tile_cells, r);
+            CK(hipDeviceSynchronize());
+            const unsigned grid = (unsigned)(c.n / 4ull / 512);
+            float total = 0;
+            for (int k = 0; k < 8; ++k) {
+                StreamArgs& a = (k & 1) ? c.bwd : c.fwd;
+                CK(hipEventRecord(c.e0));
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), 0, 0, a, c.U);
+                CK(hipEventRecord(c.e1));
+                CK(hipEventSynchronize(c.e1));
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, c.e0, c.e1));
+                if (k >= 2) total += ms;
+            }
+            CK(hipGetLastError());
+            printf("%-28s steps 2..7 after the sort: %8.4f ms average\n", name, total / 6);
+            fflush(stdout);
+        };
+        if (c.n * 4ull >= (1ull << 32)) { printf("arrays too large for 32-bit buffer offsets\n"); return 1; }
+        run_spol(variant_kernel<1, true, true, false, true, 512, -1, false, -1>, "nt global_load (library)");
+        run_spol(variant_kernel<1, true, true, false, true, 512, -1, false, 0>, "buffer_load plain");
+        run_spol(variant_kernel<1, true, true, false, true, 512, -1, false, 2>, "buffer_load nt");
+        run_spol(variant_kernel<1, true, true, false, true, 512, -1, false, 1>, "buffer_load sc0");
+        run_spol(variant_kernel<1, true, true, false, true, 512, -1, false, 3>, "buffer_load sc0 nt");
+        run_spol(variant_kernel<1, true, true, false, true, 512, -1, false, 16>, "buffer_load sc1");
+        run_spol(variant_kernel<1, true, true, false, true, 512, -1, false, 18>, "buffer_load sc1 nt");
+        run_spol(variant_kernel<1, true, true, false, true, 512, -1, false, 17>, "buffer_load sc0 sc1");
+        run_spol(variant_kernel<1, true, true, false, true, 512, -1, false, 19>, "buffer_load sc0 sc1 nt");
     }
     if (set == 2) {
         const unsigned tile_cells = argc > 6 ? atoi(argv[6]) : 16;
