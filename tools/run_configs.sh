@@ -1,5 +1,5 @@
 #!/bin/bash
-# The BASELINE configurations that fit one GPU, one bench.py run each; JSON lines into <outdir>.
+# The benchmark configurations that fit one GPU, one bench.py run each; JSON lines into <outdir>.
 #   bash tools/run_configs.sh gpurun_out/configs
 set -e
 OUT=$1
