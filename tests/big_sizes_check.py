@@ -17,13 +17,12 @@ from conftest import assert_particles_bit_equal, scene_swirl_field
 from oracle import oracle as O
 
 
-def check(sizes):
+def check(sizes, steps=14):
     sp = pa.SimParams()
     sp.delta_t = np.float32(1.0 / 60.0)
     sp.force_grid_dimensions = (1024, 1024, 1)
     sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
     g = scene_swirl_field(1024, 1024, 1, 10.0, seed=5)
-    steps = 14
     for log2n in sizes:
         n = 1 << log2n
         t0 = time.time()
@@ -45,4 +44,10 @@ def check(sizes):
 
 
 if __name__ == "__main__":
-    check([int(a) for a in sys.argv[1:]])
+    # usage: big_sizes_check.py [--steps K] log2n...
+    argv = sys.argv[1:]
+    k = 14
+    if argv and argv[0] == "--steps":
+        k = int(argv[1])
+        argv = argv[2:]
+    check([int(a) for a in argv], steps=k)
