@@ -66,3 +66,28 @@ def test_no_cpu_fallback_without_a_device():
         pytest.skip("a GPU is present")
     with pytest.raises(pa.PclError):
         pa.Compute.new(pa.empty_particles(4), np.zeros((1, 4), dtype=np.float32))
+
+
+def test_header_is_valid_c11_and_links_from_plain_c(tmp_path):
+    """The boundary is a C ABI: the header must compile as strict C11 and a
+    plain C program must link against the library (no C++ in the interface)."""
+    import subprocess
+    src = tmp_path / "abi_probe.c"
+    src.write_text(
+        '#include "particles_hip.h"\n'
+        '#include <stdio.h>\n'
+        'int main(void) {\n'
+        '    pcl_sim_params p; pcl_brush_input b; pcl_compute* h = 0;\n'
+        '    pcl_sim_params_default(&p); pcl_brush_input_default(&b);\n'
+        '    if (sizeof(pcl_particle) != 48 || sizeof(p) != 912 || sizeof(b) != 64) return 1;\n'
+        '    if (pcl_step(h) != PCL_ERR_INVALID) return 2;          /* null handle: status code, no crash */\n'
+        '    printf("%g %g %s\\n", (double)p.max_velocity, (double)b.falloff_dist, pcl_last_error());\n'
+        '    return 0;\n'
+        '}\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "abi_probe"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"),
+                           str(src), "-o", str(exe), "-L", os.path.join(root, "particles_amd"), "-lparticles_hip",
+                           "-Wl,-rpath," + os.path.join(root, "particles_amd"), "-Wl,-rpath-link,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe)], text=True)
+    assert out.split()[:2] == ["100", "1"]
