@@ -345,6 +345,13 @@ int pcl_timer_stop(pcl_compute* h, float* elapsed_ms);
  * fields above 64 KiB and at least 2^20 particles), 0 never, k > 0 every k steps. */
 int pcl_set_reorder_interval(pcl_compute* h, int interval);
 
+/* The interval currently in force: 0 when the order is not maintained (small
+ * sets, fields small enough for LDS, or interval 0); in automatic mode it
+ * starts at 12 and is paced by how far the particles drift between refreshes
+ * (a counting step reports how many tiles each block's particles fall into:
+ * up to 3 doubles the interval, at most to 96; 8 or more halves it again). */
+int pcl_reorder_interval_in_use(const pcl_compute* h);
+
 /* Sort by field tile now (also the first step does when reordering is on). */
 int pcl_reorder_now(pcl_compute* h);
 

@@ -308,6 +308,11 @@ class Compute:
         """-1 automatic, 0 never, k > 0: refresh the field-tile order every k steps."""
         _lib.check(self._lib.pcl_set_reorder_interval(self._h, int(interval)))
 
+    @property
+    def reorder_interval_in_use(self):
+        """Steps between refreshes of the tile order currently in force (0: none)."""
+        return int(self._lib.pcl_reorder_interval_in_use(self._h))
+
     def reorder_now(self):
         _lib.check(self._lib.pcl_reorder_now(self._h))
 

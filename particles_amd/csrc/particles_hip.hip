@@ -65,6 +65,7 @@ int fail(int code, const std::string& msg)
 constexpr size_t kStagingRecords = size_t(1) << 22;  // AoS staging chunk: 4 Mi records = 192 MiB
 constexpr uint32_t kLdsFieldMaxBytes = 64u * 1024u;  // fields up to this size are staged in LDS
 constexpr int kAutoReorderInterval = 12;               // steps between refreshes of the tile order
+constexpr int kAutoReorderMaxInterval = 96;           // automatic pacing never waits longer than this
 constexpr size_t kAutoReorderMinFieldBytes = 64u * 1024u;        // smaller fields are staged in LDS instead
 constexpr size_t kAutoReorderMinParticles = size_t(1) << 20;
 constexpr size_t kPairBinnedMinParticles = size_t(1) << 15;  // automatic switch to the cell-binned pair kernel
@@ -105,6 +106,13 @@ struct pcl_compute {
     bool hist_valid = false;           // d_hist counts the tile keys of state[cur] (left by a counting step)
     pcl::TileMap hist_tiles;           // the key function that histogram was taken with
     uint64_t reorders = 0;
+    // automatic pacing of the refreshes (reorder_interval == -1)
+    int auto_interval = 0;             // current interval; 0 until first used
+    uint32_t* d_runs = nullptr;        // bins touched per block, summed by the counting step
+    uint32_t* h_runs = nullptr;        // pinned host copy
+    hipEvent_t ev_runs = nullptr;      // recorded after the copy into h_runs
+    bool runs_pending = false;
+    uint64_t runs_tiles = 0;           // blocks of the counting step that produced *h_runs
 
     pcl::f32x4* field = nullptr;
     size_t n_cells = 0;
@@ -422,7 +430,8 @@ int effective_reorder_interval(const pcl_compute* h)
     if (use_lds_field(h)) return 0;                       // the whole field sits in LDS: order is irrelevant
     if (h->reorder_interval >= 0) return h->reorder_interval;
     const size_t field_bytes = h->n_cells * sizeof(pcl::f32x4);
-    return (field_bytes > kAutoReorderMinFieldBytes && h->n >= kAutoReorderMinParticles) ? kAutoReorderInterval : 0;
+    if (!(field_bytes > kAutoReorderMinFieldBytes && h->n >= kAutoReorderMinParticles)) return 0;
+    return h->auto_interval > 0 ? h->auto_interval : kAutoReorderInterval;
 }
 
 int reserve_reorder(pcl_compute* h)
@@ -584,6 +593,26 @@ bool use_binned_pairs(const pcl_compute* h)
     return h->n >= kPairBinnedMinParticles && make_pair_cell_map(p).n_bins >= 27;
 }
 
+// Automatic pacing: a counting step leaves the number of (block, bin) pairs its
+// output touches.  About one or two per block means the order has not decayed
+// yet and the next refresh can wait twice as long; many mean it should come
+// sooner again.  The value arrives asynchronously (pinned copy + event) and is
+// applied to the cycles after the one that measured it.  The order never
+// affects results, only how well the field fetches hit the caches.
+void poll_refresh_pacing(pcl_compute* h)
+{
+    if (!h->runs_pending || hipEventQuery(h->ev_runs) != hipSuccess) return;
+    h->runs_pending = false;
+    if (h->reorder_interval >= 0 || h->runs_tiles == 0) return;
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < pcl::kRunSlots; ++k) total += h->h_runs[k];
+    const double per_block = (double)total / (double)h->runs_tiles;
+    int iv = h->auto_interval > 0 ? h->auto_interval : kAutoReorderInterval;
+    if (per_block <= 3.0) iv = std::min(iv * 2, kAutoReorderMaxInterval);
+    else if (per_block >= 8.0) iv = std::max(iv / 2, kAutoReorderInterval);
+    h->auto_interval = iv;
+}
+
 int do_step_impl(pcl_compute* h, int* kind)
 {
     if (int rc = bind(h)) return rc;
@@ -606,6 +635,7 @@ int do_step_impl(pcl_compute* h, int* kind)
 
     bool flipped = false;   // the launch already flipped the buffers
     if (!use_pairs) {
+        poll_refresh_pacing(h);
         const int interval = effective_reorder_interval(h);
         const bool sort_now = interval > 0 && (!h->sorted || h->steps_since_sort >= (uint64_t)interval);
         // A pending histogram fixes the key function (delta_t, hence the lookahead, may change per frame).
@@ -644,6 +674,12 @@ int do_step_impl(pcl_compute* h, int* kind)
                 // neighbouring tiles, which is what keeps the field fetches cache-resident
                 // (a persistent grid striding over the array measured 15 % slower).
                 PCL_HIP_TRY(hipMemsetAsync(h->d_hist, 0, T.n_bins * sizeof(uint32_t), h->stream));
+                if (!h->d_runs) {
+                    PCL_HIP_TRY(hipMalloc((void**)&h->d_runs, pcl::kRunSlots * sizeof(uint32_t)));
+                    PCL_HIP_TRY(hipHostMalloc((void**)&h->h_runs, pcl::kRunSlots * sizeof(uint32_t), hipHostMallocDefault));
+                    PCL_HIP_TRY(hipEventCreateWithFlags(&h->ev_runs, hipEventDisableTiming));
+                }
+                PCL_HIP_TRY(hipMemsetAsync(h->d_runs, 0, pcl::kRunSlots * sizeof(uint32_t), h->stream));
             }
             if (h->step_diag)
                 if (int rc = reserve_partials(h, grid)) return rc;
@@ -655,6 +691,7 @@ int do_step_impl(pcl_compute* h, int* kind)
             a.n = h->n;
             a.partials = h->d_partials;
             a.hist = h->d_hist;
+            a.runs = (count && !h->runs_pending) ? h->d_runs : nullptr;
             const bool lds = use_lds_field(h);
             a.lds_cells = lds ? (uint32_t)h->n_cells : 0u;
             // pcl_step_n: as many of the requested steps as fit before the next counting or
@@ -691,6 +728,12 @@ int do_step_impl(pcl_compute* h, int* kind)
             h->hist_valid = count;
             if (count) h->hist_tiles = T;
             if (count) *kind = PCL_STEP_STREAM_COUNT;
+            if (count && a.runs) {
+                PCL_HIP_TRY(hipMemcpyAsync(h->h_runs, h->d_runs, pcl::kRunSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+                PCL_HIP_TRY(hipEventRecord(h->ev_runs, h->stream));
+                h->runs_pending = true;
+                h->runs_tiles = grid;
+            }
             }
         }
     } else if (!gathered && use_binned_pairs(h)) {
@@ -972,6 +1015,9 @@ int pcl_destroy(pcl_compute* h)
     if (h->d_partials) (void)hipFree(h->d_partials);
     if (h->d_diag) (void)hipFree(h->d_diag);
     if (h->d_hist) (void)hipFree(h->d_hist);
+    if (h->d_runs) (void)hipFree(h->d_runs);
+    if (h->h_runs) (void)hipHostFree(h->h_runs);
+    if (h->ev_runs) (void)hipEventDestroy(h->ev_runs);
     if (h->d_brush_state) (void)hipFree(h->d_brush_state);
     if (h->d_brush_index) (void)hipFree(h->d_brush_index);
     if (h->d_brush_vector) (void)hipFree(h->d_brush_vector);
@@ -1585,6 +1631,8 @@ int pcl_set_reorder_interval(pcl_compute* h, int interval)
     h->hist_valid = false;
     return PCL_OK;
 }
+
+int pcl_reorder_interval_in_use(const pcl_compute* h) { return h ? effective_reorder_interval(h) : 0; }
 
 int pcl_reorder_now(pcl_compute* h)
 {

@@ -320,6 +320,7 @@ struct StreamArgs {
     DiagPartial* partials;  // one per block when DIAG
     uint32_t lds_cells;     // cells staged in LDS when FIELD_LDS
     uint32_t* hist;         // global tile histogram when COUNT
+    uint32_t* runs;         // when COUNT: total over blocks of the bins each block touched (may be null)
 };
 
 template <bool NT>
@@ -372,6 +373,7 @@ __device__ __forceinline__ void tile_store4(__amdgpu_buffer_rsrc_t r, uint32_t l
 #endif
 constexpr int kStreamThreads = PCL_STREAM_THREADS;
 constexpr int kStreamTile = kStreamThreads * kParticlesPerLane;
+constexpr uint32_t kRunSlots = 256;   // counters of StreamArgs::runs
 
 // COUNT: also histogram the field tile of every OUTPUT position into a.hist
 // (LDS counters per persistent block, one global atomic per non-empty bin), so
@@ -388,8 +390,10 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_kernel(StreamArgs 
         for (uint32_t c = threadIdx.x; c < a.lds_cells; c += kStreamThreads) lds_field[c] = a.field[c];
         __syncthreads();
     }
+    __shared__ uint32_t touched_sh;
     if (COUNT) {
         for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) lds_hist[b] = 0u;
+        if (threadIdx.x == 0) touched_sh = 0u;
         __syncthreads();
     }
     auto fetch = [&](uint32_t c) -> f32x4 { return FIELD_LDS ? lds_field[c] : a.field[c]; };
@@ -473,9 +477,18 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_kernel(StreamArgs 
 
     if (COUNT) {
         __syncthreads();
+        uint32_t touched = 0u;
         for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) {
             const uint32_t c = lds_hist[b];
-            if (c) atomicAdd(&a.hist[b], c);
+            if (c) { atomicAdd(&a.hist[b], c); ++touched; }
+        }
+        // How many bins this block's particles fall into: 1-2 while the order is intact, more
+        // the further they have drifted.  The host reads the total to pace the refreshes
+        // (kRunSlots counters, so that the blocks do not all hit one address).
+        if (a.runs) {
+            if (touched) atomicAdd(&touched_sh, touched);
+            lds_barrier();
+            if (threadIdx.x == 0) atomicAdd(&a.runs[blockIdx.x % kRunSlots], touched_sh);
         }
     }
     if (DIAG) block_reduce_store<kStreamThreads>(acc, a.partials + blockIdx.x);

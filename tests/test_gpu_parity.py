@@ -530,3 +530,31 @@ def test_rejected_upload_leaves_a_tile_ordered_set_intact(oracle):
             c.upload_particles(bad)
         want = oracle.run(sp, p, g, 3, mode=oracle.MODE_SKIP_INERT)
         assert_particles_bit_equal(c.read_particles(), want, "state after a rejected upload")
+
+
+@pytest.mark.parametrize("vel_extent,expect_long", [(0.0, True), (10.0, False)])
+def test_automatic_refresh_pacing_follows_the_drift(oracle, vel_extent, expect_long):
+    """Automatic mode: particles that stay put stretch the refresh interval
+    (12 -> 24 -> 48 -> 96, each change one cycle after its measurement), fast ones keep it at 12; results are unaffected."""
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = (128, 128, 1)          # 256 KiB: too large for LDS staging
+    n = 1 << 20
+    g = np.zeros((128 * 128, 4), dtype=np.float32) if expect_long else scene_swirl_field(128, 128, 1, 10.0, seed=3)
+    g[:, 3] = 1.0
+    steps = 330
+    with pa.Compute.new(pa.empty_particles(0), g) as c:
+        c.update_sim_params(sp)
+        c.generate_particles(n, seed=6, pos_extent=20.0, vel_extent=vel_extent)
+        assert c.reorder_interval_in_use == 12
+        for _ in range(steps):
+            c.compute()
+        c.synchronize()
+        for first in (0, n - 2000):
+            p = oracle.synth_particles(2000, seed=6, first_global_index=first, pos_extent=20.0, vel_extent=vel_extent)
+            want = oracle.run(sp, p, g, steps, mode=oracle.MODE_SKIP_INERT)
+            assert_particles_bit_equal(c.read_particles(first, 2000), want, f"slice at {first}")
+        if expect_long:
+            assert c.reorder_interval_in_use >= 48 and c.reorder_count <= 14       # against 27 at a fixed 12
+        else:
+            assert c.reorder_interval_in_use == 12 and c.reorder_count >= steps // 12 - 1
