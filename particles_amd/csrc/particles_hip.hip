@@ -402,6 +402,8 @@ pcl::TileMap make_tile_map(const pcl_sim_params& p, int interval, uint32_t log2_
     for (int a = 0; a < 3; ++a) T.inv_cell[a] = (side > 0.0f && std::isfinite(side)) ? (float)d[a] / side : 0.0f;
     // aim the order at the middle of the refresh interval
     T.lookahead = interval > 1 ? p.delta_t * (aim * (float)interval) : 0.0f;
+    T.reach = 0;
+    T.cell_len = 0.0f;
     return T;
 }
 
@@ -559,15 +561,22 @@ int caller_order_map(pcl_compute* h, const uint32_t** out)
 }
 
 // Uniform grid of at most 20^3 cells whose edge is at least 1.0001 x the
-// cut-off (the margin absorbs the rounding of the reciprocal-multiply key), as a
-// TileMap with unit tiles: the sort key is (cx * n + cy) * n + cz.
-pcl::TileMap make_pair_cell_map(const pcl_sim_params& p)
+// cut-off, or half of that with a sweep of two cells each way (the margin absorbs
+// the rounding of the reciprocal-multiply key), as a TileMap with unit tiles: the
+// sort key is (cx * n + cy) * n + cz.
+pcl::TileMap make_pair_cell_map(const pcl_sim_params& p, bool allow_reach2 = true)
 {
     const double side = 2.0 * (double)p.bounding_volume_radius;
     const double edge = (double)p.cut_off_distance * 1.0001;
-    uint32_t n = 1;
-    if (side > 0.0 && edge > 0.0 && std::isfinite(side) && std::isfinite(edge))
-        n = (uint32_t)std::min(20.0, std::max(1.0, std::floor(side / edge)));
+    uint32_t n = 1, reach = 1;
+    if (side > 0.0 && edge > 0.0 && std::isfinite(side) && std::isfinite(edge)) {
+        // cells of at least the cut-off swept one cell each way, or of at least half the cut-off
+        // swept two each way: whichever sweeps the smaller volume, (2 * reach + 1) / n per axis
+        const double n1 = std::min(20.0, std::max(1.0, std::floor(side / edge)));
+        const double n2 = std::min(20.0, std::max(1.0, std::floor(2.0 * side / edge)));
+        if (allow_reach2 && 5.0 / n2 < 3.0 / n1) { n = (uint32_t)n2; reach = 2; }
+        else { n = (uint32_t)n1; reach = 1; }
+    }
     pcl::TileMap C;
     C.sx = C.sy = C.sz = 0;
     C.nty = C.ntz = n;
@@ -577,6 +586,8 @@ pcl::TileMap make_pair_cell_map(const pcl_sim_params& p)
         C.inv_cell[a] = (side > 0.0 && std::isfinite(side)) ? (float)((double)n / side) : 0.0f;
     }
     C.lookahead = 0.0f;
+    C.reach = reach;
+    C.cell_len = (side > 0.0 && std::isfinite(side)) ? (float)(side / (double)n) : 0.0f;
     return C;
 }
 
@@ -746,7 +757,7 @@ int do_step_impl(pcl_compute* h, int* kind)
             h->params_dirty = false;
         }
         if (int rc = reserve_reorder(h)) return rc;
-        const pcl::TileMap C = make_pair_cell_map(h->params);
+        const pcl::TileMap C = make_pair_cell_map(h->params, (h->variant & 0x10000u) == 0);   // tuning bit: one-cell reach only
         if (int rc = reorder_count(h, U, C)) return rc;
         pcl::ReorderArgs ra;
         uint32_t sgrid = 0;

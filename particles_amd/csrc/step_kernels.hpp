@@ -278,6 +278,8 @@ struct TileMap {
     uint32_t max_ix[3];      // dim - 1 per axis (an index equal to dim is clamped)
     float lookahead;         // seconds: the key is the tile of pos + vel * lookahead
     float inv_cell[3];       // cells per unit length per axis (0 when the range is degenerate)
+    uint32_t reach;          // pair cell maps: neighbour cells to sweep each way (1 or 2); 0 otherwise
+    float cell_len;          // pair cell maps: cell edge length
 };
 
 // Sort key of a particle: the field tile of where it will be `lookahead`
@@ -782,15 +784,29 @@ __global__ __launch_bounds__(kBlockThreads) void step_pairs_binned_kernel(
         cx = cx < C.max_ix[0] ? cx : C.max_ix[0];
         cy = cy < C.max_ix[1] ? cy : C.max_ix[1];
         cz = cz < C.max_ix[2] ? cz : C.max_ix[2];
-        const uint32_t z0 = cz > 0u ? cz - 1u : 0u;
-        const uint32_t z1 = cz < C.max_ix[2] ? cz + 1u : cz;
+        // R cells each way reach every partner within the cut-off (R * cell_len >= cut-off).
+        const int R = (int)C.reach;
+        const uint32_t z0 = cz > (uint32_t)R ? cz - (uint32_t)R : 0u;
+        const uint32_t z1 = cz + (uint32_t)R < C.max_ix[2] ? cz + (uint32_t)R : C.max_ix[2];
+        // Distance from this particle to a column of cells along one axis; the outermost cells
+        // also hold the particles beyond the box, so they extend to infinity.  A thousandth of a
+        // cell is taken off for the rounding of the sort key.
+        auto axis_gap = [&](float p, int cell, uint32_t last) -> float {
+            const float lo = cell == 0 ? -INFINITY : U.neg_slh + (float)cell * C.cell_len;
+            const float hi = cell == (int)last ? INFINITY : U.neg_slh + (float)(cell + 1) * C.cell_len;
+            const float gap = fmaxf(fmaxf(lo - p, p - hi), 0.0f);
+            return fmaxf(gap - 0.001f * C.cell_len, 0.0f);
+        };
         float ax = 0.0f, ay = 0.0f, az = 0.0f;
-        for (int dx = -1; dx <= 1; ++dx) {
+        for (int dx = -R; dx <= R; ++dx) {
             const int X = (int)cx + dx;
             if (X < 0 || X > (int)C.max_ix[0]) continue;
-            for (int dy = -1; dy <= 1; ++dy) {
+            const float gx = axis_gap(x, X, C.max_ix[0]);
+            for (int dy = -R; dy <= R; ++dy) {
                 const int Y = (int)cy + dy;
                 if (Y < 0 || Y > (int)C.max_ix[1]) continue;
+                const float gy = axis_gap(y, Y, C.max_ix[1]);
+                if (gx * gx + gy * gy >= a.s_far) continue;   // no cell of this column is within the cut-off
                 const uint32_t b0 = ((uint32_t)X * C.nty + (uint32_t)Y) * C.ntz + z0;
                 const uint32_t b1 = b0 + (z1 - z0);
                 const uint32_t j0 = b0 ? bin_end[b0 - 1u] : 0u;

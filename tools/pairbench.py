@@ -16,7 +16,11 @@ def main():
     sp.polys[:] = np.random.default_rng(1).uniform(-1, 1, size=(25, 8)).astype(np.float32)
     g = sp.new_force_grid_centered().get_force_vectors()
     variants = {1: (0,), 2: (0,)}
-    for mode, variant in ((m, v) for m in (1, 2) for v in variants[m]):
+    cutoff = float(os.environ.get("PAIRBENCH_CUTOFF", "1.0"))
+    sp.cut_off_distance = cutoff
+    if "PAIRBENCH_VARIANT" in os.environ:
+        variants = {2: tuple(int(v, 0) for v in os.environ["PAIRBENCH_VARIANT"].split(","))}
+    for mode, variant in ((m, v) for m in sorted(variants) for v in variants[m]):
       for exponent in (0.0,):
         sp.distance_exponent = exponent
         for extent in (2.0, 20.0):
@@ -39,7 +43,7 @@ def main():
                         c.compute()
                     ms = c.timer_stop() / steps
                     assert c.last_step_kernel == pa.KERNEL_PAIRS
-                    print(f"mode {mode} variant {variant:#x} exponent {exponent:4.1f} extent {extent:4.1f} n {n:7d}: {ms:9.4f} ms/step  "
+                    print(f"cutoff {cutoff} mode {mode} variant {variant:#x} exponent {exponent:4.1f} extent {extent:4.1f} n {n:7d}: {ms:9.4f} ms/step  "
                           f"{n * n / ms / 1e6:9.2f} G pair visits/s", flush=True)
 
 
