@@ -406,7 +406,8 @@ def _close(got, want, two_r, rtol=1e-5, atol=1e-6):
 
 
 @pytest.mark.parametrize("n,cutoff,extent,exponent", [
-    (3000, 1.5, 20.0, 0.0), (3001, 0.7, 6.0, 0.0), (8192, 2.5, 20.0, -1.0), (257, 30.0, 20.0, 0.0), (5000, 1.0, 40.0, 0.5)])
+    (3000, 1.5, 20.0, 0.0), (3001, 0.7, 6.0, 0.0), (8192, 2.5, 20.0, -1.0), (257, 30.0, 20.0, 0.0), (5000, 1.0, 40.0, 0.5),
+    (4000, 3.0, 40.0, 0.0), (6000, 4.9, 24.0, 0.0)])   # two-cell reach, particles beyond the box
 def test_binned_pair_kernel_matches_oracle(oracle, n, cutoff, extent, exponent):
     sp = pair_params(exponent)
     sp.cut_off_distance = cutoff
