@@ -268,12 +268,14 @@ int pcl_force_pair_kernel(pcl_compute* h, int enable);
 
 /* How the pair term (src/compute.wgsl:115-144) is evaluated when it is not
  * provably zero.  PCL_PAIRS_ALL: the shader's sweep over all N particles in
- * index order (bit-exact summation order).  PCL_PAIRS_BINNED: particles are
- * sorted into cells of edge >= cut_off_distance and only the 27 surrounding
- * cells are swept: same skip tests and force expression, sums equal up to
- * fp32 summation order, O(N k) instead of O(N^2).  PCL_PAIRS_AUTO (default):
- * binned from 2^15 particles on when the cut-off allows at least 3 cells per
- * axis, the exact sweep otherwise. */
+ * index order (bit-exact summation order, reproducible).  PCL_PAIRS_BINNED:
+ * particles are sorted into cells of edge >= cut_off_distance (or half of it)
+ * and only the cells within reach are swept: same skip tests and force
+ * expression, O(N k) instead of O(N^2); a particle's terms are added in the
+ * order the sort left its partners in, so sums equal the exact sweep's up to
+ * fp32 summation order and may differ in the last bits from run to run.
+ * PCL_PAIRS_AUTO (default): binned from 2^15 particles on when the cut-off
+ * allows at least 3 cells per axis, the exact sweep otherwise. */
 enum { PCL_PAIRS_AUTO = 0, PCL_PAIRS_ALL = 1, PCL_PAIRS_BINNED = 2 };
 int pcl_set_pair_mode(pcl_compute* h, int mode);
 
