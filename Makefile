@@ -7,7 +7,7 @@ HIPFLAGS  ?= -O3 --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math -fPIC -
 
 LIB       := particles_amd/libparticles_hip.so
 SRC       := particles_amd/csrc/particles_hip.hip
-HDRS      := particles_amd/csrc/step_kernels.hpp particles_amd/csrc/reorder_kernels.hpp include/particles_hip.h
+HDRS      := particles_amd/csrc/step_kernels.hpp particles_amd/csrc/reorder_kernels.hpp particles_amd/csrc/brush_kernels.hpp include/particles_hip.h
 
 CPPTEST   := tests/cpp/compute_wrapper_test
 

@@ -21,7 +21,8 @@ fn main() {
     println!("cargo:rustc-link-search=native={}", out.display());
     println!("cargo:rustc-link-lib=dylib=particles_hip");
     for f in ["particles_amd/csrc/particles_hip.hip", "particles_amd/csrc/step_kernels.hpp",
-              "particles_amd/csrc/reorder_kernels.hpp", "include/particles_hip.h"] {
+              "particles_amd/csrc/reorder_kernels.hpp", "particles_amd/csrc/brush_kernels.hpp",
+              "include/particles_hip.h"] {
         println!("cargo:rerun-if-changed={}", repo.join(f).display());
     }
 }
