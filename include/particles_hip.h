@@ -274,6 +274,7 @@ int pcl_force_pair_kernel(pcl_compute* h, int enable);
  * expression, O(N k) instead of O(N^2); a particle's terms are added in the
  * order the sort left its partners in, so sums equal the exact sweep's up to
  * fp32 summation order and may differ in the last bits from run to run.
+ * At most 20 cells per axis, 64 from 2^18 particles on.
  * PCL_PAIRS_AUTO (default): binned from 2^15 particles on when the cut-off
  * allows at least 3 cells per axis, the exact sweep otherwise. */
 enum { PCL_PAIRS_AUTO = 0, PCL_PAIRS_ALL = 1, PCL_PAIRS_BINNED = 2 };

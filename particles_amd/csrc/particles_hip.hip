@@ -65,6 +65,8 @@ int fail(int code, const std::string& msg)
 constexpr size_t kStagingRecords = size_t(1) << 22;  // AoS staging chunk: 4 Mi records = 192 MiB
 constexpr uint32_t kLdsFieldMaxBytes = 64u * 1024u;  // fields up to this size are staged in LDS
 constexpr int kAutoReorderInterval = 12;               // steps between refreshes of the tile order
+constexpr size_t kPairWideMinParticles = size_t(1) << 18;   // below: the sort over many cells costs more than the sweep saves
+constexpr uint32_t kPairMaxCellsPerAxis = 64;          // cut-off cells per axis (beyond 20: counters in global memory)
 constexpr int kAutoReorderMaxInterval = 96;           // automatic pacing never waits longer than this
 constexpr size_t kAutoReorderMinFieldBytes = 64u * 1024u;        // smaller fields are staged in LDS instead
 constexpr size_t kAutoReorderMinParticles = size_t(1) << 20;
@@ -106,6 +108,11 @@ struct pcl_compute {
     bool hist_valid = false;           // d_hist counts the tile keys of state[cur] (left by a counting step)
     pcl::TileMap hist_tiles;           // the key function that histogram was taken with
     uint64_t reorders = 0;
+    // counting sort with global counters (pair cells beyond kMaxReorderBins)
+    uint32_t* d_wide = nullptr;        // histogram[bins + 1] then start[bins + 1]
+    size_t wide_bins = 0;
+    uint32_t* d_keyrank = nullptr;     // key[capacity] then rank[capacity]
+    size_t keyrank_capacity = 0;
     // automatic pacing of the refreshes (reorder_interval == -1)
     int auto_interval = 0;             // current interval; 0 until first used
     uint32_t* d_runs = nullptr;        // bins touched per block, summed by the counting step
@@ -468,6 +475,62 @@ int reorder_count(pcl_compute* h, const pcl::StepUniforms& U, const pcl::TileMap
     return PCL_OK;
 }
 
+// Source and destination arrays of a scatter from state[cur] into state[cur ^ 1].
+void reorder_args(const pcl_compute* h, pcl::ReorderArgs* a)
+{
+    const int src = h->cur, dst = h->cur ^ 1;
+    for (int k = 0; k < 6; ++k) { a->src[k] = h->state[src][k]; a->dst[k] = h->state[dst][k]; }
+    a->src_ty = h->ty_buf[h->ty_cur];
+    a->dst_ty = h->ty_buf[h->ty_cur ^ 1];
+    a->src_orig = h->sorted ? h->orig[h->orig_cur] : nullptr;
+    a->dst_orig = h->orig[h->sorted ? (h->orig_cur ^ 1) : 0];
+    a->cursor = nullptr;
+    a->n = h->n;
+}
+
+// Counting sort of state[cur] into state[cur ^ 1] by the keys of `C` with the
+// counters in global memory; leaves start[0 .. n_bins] (start[n_bins] = n) and
+// returns a pointer to it.
+int wide_sort(pcl_compute* h, const pcl::StepUniforms& U, const pcl::TileMap& C, const uint32_t** start_out)
+{
+    const size_t entries = (size_t)C.n_bins + 1;
+    if (h->wide_bins < entries) {
+        PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->d_wide) PCL_HIP_TRY(hipFree(h->d_wide));
+        h->d_wide = nullptr;
+        h->wide_bins = 0;
+        PCL_HIP_TRY(hipMalloc((void**)&h->d_wide, 2 * entries * sizeof(uint32_t)));
+        h->wide_bins = entries;
+    }
+    if (h->keyrank_capacity < h->capacity) {
+        PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->d_keyrank) PCL_HIP_TRY(hipFree(h->d_keyrank));
+        h->d_keyrank = nullptr;
+        h->keyrank_capacity = 0;
+        PCL_HIP_TRY(hipMalloc((void**)&h->d_keyrank, 2 * h->capacity * sizeof(uint32_t)));
+        h->keyrank_capacity = h->capacity;
+    }
+    uint32_t* hist = h->d_wide;
+    uint32_t* start = h->d_wide + h->wide_bins;
+    uint32_t* key = h->d_keyrank;
+    uint32_t* rank = h->d_keyrank + h->keyrank_capacity;
+    PCL_HIP_TRY(hipMemsetAsync(hist, 0, entries * sizeof(uint32_t), h->stream));
+    hipLaunchKernelGGL(pcl::wide_key_rank_kernel, dim3(linear_grid(h, h->n)), dim3(pcl::kBlockThreads), 0, h->stream,
+                       soa_of(h, h->cur), (unsigned long long)h->n, U, C, hist, key, rank);
+    PCL_HIP_TRY(hipGetLastError());
+    // the extra zero entry makes the scan leave the total, n, in start[n_bins]
+    hipLaunchKernelGGL(pcl::reorder_scan_kernel, dim3(1), dim3(1024), 0, h->stream, (const uint32_t*)hist,
+                       (uint32_t)entries, start);
+    PCL_HIP_TRY(hipGetLastError());
+    pcl::ReorderArgs ra;
+    reorder_args(h, &ra);
+    hipLaunchKernelGGL(pcl::wide_scatter_kernel, dim3(linear_grid(h, h->n)), dim3(pcl::kBlockThreads), 0, h->stream,
+                       ra, (const uint32_t*)start, (const uint32_t*)key, (const uint32_t*)rank);
+    PCL_HIP_TRY(hipGetLastError());
+    *start_out = start;
+    return PCL_OK;
+}
+
 // Exclusive scan of d_hist into the cursors and the argument block of a
 // scatter from state[cur] into state[cur ^ 1].
 int reorder_prepare(pcl_compute* h, const pcl::TileMap& T, pcl::ReorderArgs* a, uint32_t* grid)
@@ -476,14 +539,8 @@ int reorder_prepare(pcl_compute* h, const pcl::TileMap& T, pcl::ReorderArgs* a, 
     uint32_t* cursor = h->d_hist + pcl::kMaxReorderBins;
     hipLaunchKernelGGL(pcl::reorder_scan_kernel, dim3(1), dim3(1024), 0, h->stream, hist, T.n_bins, cursor);
     PCL_HIP_TRY(hipGetLastError());
-    const int src = h->cur, dst = h->cur ^ 1;
-    for (int k = 0; k < 6; ++k) { a->src[k] = h->state[src][k]; a->dst[k] = h->state[dst][k]; }
-    a->src_ty = h->ty_buf[h->ty_cur];
-    a->dst_ty = h->ty_buf[h->ty_cur ^ 1];
-    a->src_orig = h->sorted ? h->orig[h->orig_cur] : nullptr;
-    a->dst_orig = h->orig[h->sorted ? (h->orig_cur ^ 1) : 0];
+    reorder_args(h, a);
     a->cursor = cursor;
-    a->n = h->n;
     const size_t full_tiles = (h->n / 4 + pcl::kStreamThreads - 1) / pcl::kStreamThreads;
     const size_t g = full_tiles + ((h->n % 4) ? 1 : 0);   // one extra block carries the ragged tail
     PCL_REQUIRE(g >= 1 && g <= 0x7FFFFFFFu, "too many particles to reorder");
@@ -564,7 +621,7 @@ int caller_order_map(pcl_compute* h, const uint32_t** out)
 // cut-off, or half of that with a sweep of two cells each way (the margin absorbs
 // the rounding of the reciprocal-multiply key), as a TileMap with unit tiles: the
 // sort key is (cx * n + cy) * n + cz.
-pcl::TileMap make_pair_cell_map(const pcl_sim_params& p, bool allow_reach2 = true)
+pcl::TileMap make_pair_cell_map(const pcl_sim_params& p, bool allow_reach2 = true, uint32_t max_axis = 20)
 {
     const double side = 2.0 * (double)p.bounding_volume_radius;
     const double edge = (double)p.cut_off_distance * 1.0001;
@@ -572,8 +629,9 @@ pcl::TileMap make_pair_cell_map(const pcl_sim_params& p, bool allow_reach2 = tru
     if (side > 0.0 && edge > 0.0 && std::isfinite(side) && std::isfinite(edge)) {
         // cells of at least the cut-off swept one cell each way, or of at least half the cut-off
         // swept two each way: whichever sweeps the smaller volume, (2 * reach + 1) / n per axis
-        const double n1 = std::min(20.0, std::max(1.0, std::floor(side / edge)));
-        const double n2 = std::min(20.0, std::max(1.0, std::floor(2.0 * side / edge)));
+        const double cap = (double)max_axis;
+        const double n1 = std::min(cap, std::max(1.0, std::floor(side / edge)));
+        const double n2 = std::min(cap, std::max(1.0, std::floor(2.0 * side / edge)));
         if (allow_reach2 && 5.0 / n2 < 3.0 / n1) { n = (uint32_t)n2; reach = 2; }
         else { n = (uint32_t)n1; reach = 1; }
     }
@@ -757,14 +815,24 @@ int do_step_impl(pcl_compute* h, int* kind)
             h->params_dirty = false;
         }
         if (int rc = reserve_reorder(h)) return rc;
-        const pcl::TileMap C = make_pair_cell_map(h->params, (h->variant & 0x10000u) == 0);   // tuning bit: one-cell reach only
-        if (int rc = reorder_count(h, U, C)) return rc;
-        pcl::ReorderArgs ra;
-        uint32_t sgrid = 0;
-        if (int rc = reorder_prepare(h, C, &ra, &sgrid)) return rc;
-        hipLaunchKernelGGL(pcl::reorder_scatter_kernel, dim3(sgrid), dim3(pcl::kStreamThreads),
-                           pcl::scatter_lds_bytes(C.n_bins), h->stream, ra, U, C);
-        PCL_HIP_TRY(hipGetLastError());
+        // tuning bits: 0x10000 one-cell reach only, 0x20000 at most 20 cells per axis
+        const pcl::TileMap C = make_pair_cell_map(h->params, (h->variant & 0x10000u) == 0,
+                                                  ((h->variant & 0x20000u) || h->n < kPairWideMinParticles) ? 20u : kPairMaxCellsPerAxis);
+        const uint32_t* bin_end = nullptr;   // bin_end[b]: one past the last slot of cell b
+        if (C.n_bins > pcl::kMaxReorderBins) {
+            const uint32_t* start = nullptr;
+            if (int rc = wide_sort(h, U, C, &start)) return rc;
+            bin_end = start + 1;
+        } else {
+            if (int rc = reorder_count(h, U, C)) return rc;
+            pcl::ReorderArgs ra;
+            uint32_t sgrid = 0;
+            if (int rc = reorder_prepare(h, C, &ra, &sgrid)) return rc;
+            hipLaunchKernelGGL(pcl::reorder_scatter_kernel, dim3(sgrid), dim3(pcl::kStreamThreads),
+                               pcl::scatter_lds_bytes(C.n_bins), h->stream, ra, U, C);
+            PCL_HIP_TRY(hipGetLastError());
+            bin_end = h->d_hist + pcl::kMaxReorderBins;   // the cursors after the scatter
+        }
         reorder_commit(h);
         h->steps_since_sort = 0;
         const size_t blocks = (h->n + pcl::kBlockThreads - 1) / pcl::kBlockThreads;
@@ -783,7 +851,6 @@ int do_step_impl(pcl_compute* h, int* kind)
         a.s_near = smallest_square_with([](float len) { return !(len < 0.001f); });
         const float cut = h->params.cut_off_distance;
         a.s_far = smallest_square_with([cut](float len) { return len > cut; });
-        const uint32_t* bin_end = h->d_hist + pcl::kMaxReorderBins;   // the cursors after the scatter
         if (h->step_diag)
             hipLaunchKernelGGL((pcl::step_pairs_binned_kernel<true>), dim3(grid), dim3(pcl::kBlockThreads), 0,
                                h->stream, a, U, C, bin_end);
@@ -1027,6 +1094,8 @@ int pcl_destroy(pcl_compute* h)
     if (h->d_diag) (void)hipFree(h->d_diag);
     if (h->d_hist) (void)hipFree(h->d_hist);
     if (h->d_runs) (void)hipFree(h->d_runs);
+    if (h->d_wide) (void)hipFree(h->d_wide);
+    if (h->d_keyrank) (void)hipFree(h->d_keyrank);
     if (h->h_runs) (void)hipHostFree(h->h_runs);
     if (h->ev_runs) (void)hipEventDestroy(h->ev_runs);
     if (h->d_brush_state) (void)hipFree(h->d_brush_state);

@@ -352,6 +352,39 @@ __global__ __launch_bounds__(kStreamThreads) void step_scatter_kernel(StepScatte
     if (DIAG) block_reduce_store<kStreamThreads>(acc, sa.partials + blockIdx.x);
 }
 
+// Counting sort with the counters in global memory, for key spaces too large
+// for the LDS tables of the kernels above (the cut-off cells of the pair term:
+// up to 64^3).  One global atomic per particle gives its rank within its bin;
+// slower per particle than the tiled scatter, which does not matter next to
+// the pair sweep it serves.
+__global__ __launch_bounds__(kBlockThreads) void wide_key_rank_kernel(
+    StateSoA s, unsigned long long n, StepUniforms U, TileMap T, uint32_t* __restrict__ hist,
+    uint32_t* __restrict__ key, uint32_t* __restrict__ rank)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x; i < n; i += stride) {
+        const uint32_t k = tile_key(U, T, s.a[0][i], s.a[1][i], s.a[2][i], 0.0f, 0.0f, 0.0f);
+        key[i] = k;
+        rank[i] = atomicAdd(&hist[k], 1u);
+    }
+}
+
+// start[] is the exclusive prefix of the histogram that wide_key_rank_kernel filled.
+__global__ __launch_bounds__(kBlockThreads) void wide_scatter_kernel(
+    ReorderArgs a, const uint32_t* __restrict__ start, const uint32_t* __restrict__ key,
+    const uint32_t* __restrict__ rank)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x; i < a.n; i += stride) {
+        unsigned long long slot = (unsigned long long)start[key[i]] + rank[i];
+        if (slot >= a.n) slot = a.n - 1ull;   // cannot happen while histogram and keys agree; never write out of bounds
+#pragma unroll
+        for (int c = 0; c < 6; ++c) a.dst[c][slot] = a.src[c][i];
+        a.dst_ty[slot] = a.src_ty[i];
+        a.dst_orig[slot] = a.src_orig ? a.src_orig[i] : (uint32_t)i;
+    }
+}
+
 // slot_of[orig[i]] = i: where each caller index lives.
 __global__ __launch_bounds__(kBlockThreads) void invert_permutation_kernel(
     const uint32_t* __restrict__ orig, unsigned long long n, uint32_t* __restrict__ slot_of)

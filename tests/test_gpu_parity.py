@@ -427,6 +427,26 @@ def test_binned_pair_kernel_matches_oracle(oracle, n, cutoff, extent, exponent):
     assert np.array_equal(got["ty"], want["ty"])
 
 
+def test_binned_pairs_many_cells_sorted_with_global_counters(oracle):
+    """From 2^18 particles on the cut-off cells may number up to 64 per axis
+    (sorted with counters in global memory): slices against the oracle, which
+    sums over all particles."""
+    sp = pair_params(0.0)
+    sp.cut_off_distance = 0.45
+    sp.polys[:] *= np.float32(0.2)
+    g = sp.new_force_grid_centered().get_force_vectors()
+    n = 1 << 18
+    p = oracle.synth_particles(n, seed=31, pos_extent=22.0, vel_extent=3.0)   # some particles beyond the box
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        c.compute()                              # automatic mode: binned, 64^3 cells, two-cell reach
+        assert c.last_step_kernel == pa.KERNEL_PAIRS
+        got = np.concatenate([c.read_particles(0, 300), c.read_particles(n - 300, 300)])
+    want = np.concatenate([oracle.step_range(sp, p, g, 0, 300), oracle.step_range(sp, p, g, n - 300, 300)])
+    dv = np.abs(want["vel"][:, :3] - np.concatenate([p[:300], p[-300:]])["vel"][:, :3] * np.float32(np.exp(-float(sp.delta_t)))).max()
+    _close(got, want, 2.0 * sp.bounding_volume_radius, atol=1e-6 + 1e-5 * float(dv))
+
+
 def test_binned_and_exact_pair_kernels_agree_over_steps(oracle):
     sp = pair_params(0.0)
     sp.polys[:] *= np.float32(0.05)          # gentle forces: keep the 3-step horizon short of chaos
