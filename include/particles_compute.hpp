@@ -126,6 +126,9 @@ public:
         check(pcl_step_pairs_gathered(h_, dev_sources, n_sources));
     }
 
+    // All records in memory order (an instance stream does not care): one streaming pass.
+    void pack_particles_device_unordered(void* dev_out) { check(pcl_pack_particles_device_unordered(h_, dev_out)); }
+
     Diagnostics diagnostics()
     {
         Diagnostics d;

@@ -307,6 +307,13 @@ int pcl_read_soa(pcl_compute* h, size_t first, size_t count,
  * renderer's instance layout (src/main.rs:86-107, src/renderer.rs:253-257). */
 int pcl_pack_particles_device(pcl_compute* h, void* dev_out, size_t first, size_t count);
 
+/* All n records in whatever order the particles currently have in memory
+ * (every particle exactly once).  An instance stream does not care about the
+ * order of its instances (src/renderer.rs:253-257 draws them all), and this
+ * is a straight streaming pass even while the particles are kept in field-tile
+ * order.  dev_out must hold n records. */
+int pcl_pack_particles_device_unordered(pcl_compute* h, void* dev_out);
+
 /* Diagnostics of the latest state, synchronous.  Uses the fused result when
  * step diagnostics are enabled and current, otherwise runs a reduction. */
 int pcl_diagnostics_read(pcl_compute* h, pcl_diagnostics* out);

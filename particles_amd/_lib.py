@@ -82,6 +82,7 @@ SIGNATURES = {
     "pcl_read_particles": (_i, [_vp, _vp, _sz, _sz]),
     "pcl_read_soa": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcl_pack_particles_device": (_i, [_vp, _vp, _sz, _sz]),
+    "pcl_pack_particles_device_unordered": (_i, [_vp, _vp]),
     "pcl_diagnostics_read": (_i, [_vp, C.POINTER(Diagnostics)]),
     "pcl_diagnostics_device": (_i, [_vp, _vp]),
     "pcl_debug_cell_indices": (_i, [_vp, _vp, _sz, _sz]),

@@ -223,6 +223,11 @@ class Compute:
             count = self.num_particles - first
         _lib.check(self._lib.pcl_pack_particles_device(self._h, C.c_void_p(int(dev_ptr)), int(first), int(count)))
 
+    def pack_particles_device_unordered(self, dev_ptr):
+        """All records in current memory order (every particle once): what an
+        instance stream needs, as one streaming pass."""
+        _lib.check(self._lib.pcl_pack_particles_device_unordered(self._h, C.c_void_p(int(dev_ptr))))
+
     def diagnostics(self):
         d = _lib.Diagnostics()
         _lib.check(self._lib.pcl_diagnostics_read(self._h, C.byref(d)))

@@ -1572,11 +1572,32 @@ int pcl_pack_particles_device(pcl_compute* h, void* dev_out, size_t first, size_
     if (int rc = check_range(first, count, h->n, "pcl_pack_particles_device")) return rc;
     if (count == 0) return PCL_OK;
     PCL_REQUIRE(dev_out != nullptr, "pcl_pack_particles_device: dev_out is null");
+    if (h->sorted && count >= h->n / 8) {
+        // Tile order and a large range: walk the slots and write every record at its caller index.
+        hipLaunchKernelGGL(pcl::pack_aos_by_slot_kernel, dim3(linear_grid(h, h->n)), dim3(pcl::kBlockThreads), 0,
+                           h->stream, soa_of(h, h->cur), (const uint8_t*)cur_ty(h),
+                           (const uint32_t*)h->orig[h->orig_cur], (unsigned long long)h->n, (unsigned long long)first,
+                           (unsigned long long)count, reinterpret_cast<pcl::ParticleAoS*>(dev_out));
+        PCL_HIP_TRY(hipGetLastError());
+        return PCL_OK;
+    }
     const uint32_t* slot_of = nullptr;
     if (int rc = caller_order_map(h, &slot_of)) return rc;
     hipLaunchKernelGGL(pcl::pack_aos_kernel, dim3(linear_grid(h, count)), dim3(pcl::kBlockThreads), 0,
                        h->stream, soa_of(h, h->cur), (const uint8_t*)cur_ty(h), slot_of, (unsigned long long)first,
                        (unsigned long long)count, reinterpret_cast<pcl::ParticleAoS*>(dev_out));
+    PCL_HIP_TRY(hipGetLastError());
+    return PCL_OK;
+}
+
+int pcl_pack_particles_device_unordered(pcl_compute* h, void* dev_out)
+{
+    if (int rc = bind(h)) return rc;
+    if (h->n == 0) return PCL_OK;
+    PCL_REQUIRE(dev_out != nullptr, "pcl_pack_particles_device_unordered: dev_out is null");
+    hipLaunchKernelGGL(pcl::pack_aos_kernel, dim3(linear_grid(h, h->n)), dim3(pcl::kBlockThreads), 0,
+                       h->stream, soa_of(h, h->cur), (const uint8_t*)cur_ty(h), (const uint32_t*)nullptr,
+                       0ull, (unsigned long long)h->n, reinterpret_cast<pcl::ParticleAoS*>(dev_out));
     PCL_HIP_TRY(hipGetLastError());
     return PCL_OK;
 }

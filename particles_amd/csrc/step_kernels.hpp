@@ -916,6 +916,29 @@ __global__ __launch_bounds__(kBlockThreads) void pack_pair_sources_kernel(
     }
 }
 
+// The same records for particles kept in tile order, walking the slots (coalesced
+// reads) and writing each record at its caller index: one scattered 48-byte write
+// per particle instead of seven scattered reads.  `orig[i]` is the caller index of
+// slot i; records outside [first, first + count) are skipped.
+__global__ __launch_bounds__(kBlockThreads) void pack_aos_by_slot_kernel(
+    StateSoA s, const uint8_t* __restrict__ ty, const uint32_t* __restrict__ orig, unsigned long long n,
+    unsigned long long first, unsigned long long count, ParticleAoS* __restrict__ out)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x; i < n; i += stride) {
+        const unsigned long long o = orig ? orig[i] : i;
+        if (o < first || o - first >= count) continue;
+        const f32x4 p = {s.a[0][i], s.a[1][i], s.a[2][i], 1.0f};
+        const f32x4 v = {s.a[3][i], s.a[4][i], s.a[5][i], 1.0f};
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 t = {(uint32_t)ty[i], 0u, 0u, 0u};
+        ParticleAoS* r = out + (o - first);
+        *reinterpret_cast<f32x4*>(r->pos) = p;
+        *reinterpret_cast<f32x4*>(r->vel) = v;
+        *reinterpret_cast<u32x4*>(&r->ty) = t;
+    }
+}
+
 __global__ __launch_bounds__(kBlockThreads) void cell_index_kernel(
     StateSoA s, const uint32_t* __restrict__ slot_of, unsigned long long first,
     unsigned long long count, StepUniforms U, uint32_t* __restrict__ out)

@@ -172,3 +172,42 @@ def test_sharded_device_brush_over_rccl(oracle, one_rank_rccl):
         sc.close()
     assert got_g.tobytes() == want_g.tobytes()
     assert_particles_bit_equal(got_p, want_p, "sharded device brush over RCCL")
+
+
+@pytest.mark.parametrize("tile_order", [False, True])
+def test_instance_stream_pack_on_the_device(oracle, tile_order):
+    """pcl_pack_particles_device[_unordered]: the 48-byte records the renderer
+    reads (src/main.rs:86-107), written into device memory, in caller order
+    (whole set, large and small ranges) and in memory order."""
+    import torch
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = (64, 64, 1)
+    g = scene_swirl_field(64, 64, 1, 10.0, seed=6)
+    n = 20003
+    p = oracle.synth_particles(n, seed=14, pos_extent=20.0, vel_extent=10.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        c.set_reorder_interval(2 if tile_order else 0)
+        for _ in range(3):
+            c.compute()
+        assert (c.reorder_count > 0) == tile_order
+        want = oracle.run(sp, p, g, 3, mode=oracle.MODE_SKIP_INERT).view(np.uint8).reshape(n, 48)
+        buf = torch.zeros((n, 48), dtype=torch.uint8, device="cuda")
+        for first, count in ((0, n), (5, n - 9), (1000, 700), (n - 1, 1)):
+            buf.zero_()
+            torch.cuda.synchronize()
+            c.pack_particles_device(buf.data_ptr(), first, count)
+            c.synchronize()
+            got = buf.cpu().numpy()
+            assert got[:count].tobytes() == want[first:first + count].tobytes(), (first, count)
+            assert not got[count:].any()                    # nothing written past the range
+        buf.zero_()
+        torch.cuda.synchronize()
+        c.pack_particles_device_unordered(buf.data_ptr())
+        c.synchronize()
+        got = buf.cpu().numpy()
+        key = lambda a: a[np.lexsort(a.T[::-1])]            # every record exactly once, any order
+        assert key(got).tobytes() == key(want).tobytes()
+        if not tile_order:
+            assert got.tobytes() == want.tobytes()
