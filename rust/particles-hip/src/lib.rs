@@ -31,6 +31,8 @@ extern "C" {
     fn pcl_step_dt(h: *mut PclCompute, delta_t: f32) -> c_int;
     fn pcl_read_particles(h: *mut PclCompute, out: *mut c_void, first: usize, count: usize) -> c_int;
     fn pcl_pack_particles_device(h: *mut PclCompute, dev_out: *mut c_void, first: usize, count: usize) -> c_int;
+    fn pcl_pack_particles_device_unordered(h: *mut PclCompute, dev_out: *mut c_void) -> c_int;
+    fn pcl_step_n(h: *mut PclCompute, n_steps: u64) -> c_int;
     fn pcl_synchronize(h: *mut PclCompute) -> c_int;
     fn pcl_brush_input_default(out: *mut BrushInput);
     fn pcl_brush_mouse_down(h: *mut PclCompute, input: *const BrushInput) -> c_int;
@@ -142,6 +144,16 @@ impl Compute {
     /// into a device buffer shared with the graphics API.
     pub fn pack_particles_device(&mut self, dev_out: *mut c_void, first: usize, count: usize) {
         check(unsafe { pcl_pack_particles_device(self.handle, dev_out, first, count) });
+    }
+
+    /// All instance records in memory order (the renderer draws them all, order is irrelevant).
+    pub fn pack_particles_device_unordered(&mut self, dev_out: *mut c_void) {
+        check(unsafe { pcl_pack_particles_device_unordered(self.handle, dev_out) });
+    }
+
+    /// `n` updates without looking at the state in between (headless runs).
+    pub fn compute_n(&mut self, n_steps: u64) {
+        check(unsafe { pcl_step_n(self.handle, n_steps) });
     }
 
     pub fn synchronize(&mut self) {
