@@ -24,7 +24,7 @@ def check(sizes, steps=14):
     sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
     g = scene_swirl_field(1024, 1024, 1, 10.0, seed=5)
     for log2n in sizes:
-        n = 1 << log2n
+        n = (1 << log2n) + (5 if log2n >= 32 else 0)   # from 2^32 on: ragged, element indices beyond 32 bits, no tile order
         t0 = time.time()
         with pa.Compute.new(pa.empty_particles(0), g) as c:
             c.update_sim_params(sp)
@@ -33,7 +33,7 @@ def check(sizes, steps=14):
                 c.compute()
             c.synchronize()
             print(f"2^{log2n}: {steps} steps done in {time.time() - t0:.1f} s, reorders {c.reorder_count}", flush=True)
-            assert c.reorder_count >= 2
+            assert c.reorder_count >= 2 or log2n >= 32   # caller indices are 32-bit: no tile order from 2^32 - 1 particles on
             for first in (0, n // 2 - 1000, n // 2 + 123456789 % (n // 4), n - 3000):
                 p = O.synth_particles(3000, seed=99, first_global_index=first, pos_extent=20.0, vel_extent=10.0)
                 want = O.run(sp, p, g, steps, mode=O.MODE_SKIP_INERT)
