@@ -63,10 +63,12 @@ def _worker(rank, world, port, out_dir):
         sc.update_force_grid(grid0 if rank == 0 else None)
         sc.compute()
         full2 = sc.gather_particles()
+        sc.compute_n(3)                      # three updates without looking in between
+        full3 = sc.gather_particles()
         sc2 = pa.ShardedCompute.new(None, grid0 if rank == 0 else None, compute_cls=OracleCompute,
                                     n_total=777, seed=11, pos_extent=20.0)
         gen = sc2.gather_particles()
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), full=full, full2=full2, gen=gen,
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), full=full, full2=full2, full3=full3, gen=gen,
                  count=diag["count"], ke=diag["kinetic_energy"], pos_max=diag["pos_max"], pos_min=diag["pos_min"])
         sc.close()
         sc2.close()
@@ -92,12 +94,14 @@ def test_two_rank_sharding_matches_unsharded(tmp_path, oracle):
     want = oracle.run(sp, want, g2, 1, mode=oracle.MODE_SKIP_INERT)
     want_diag = oracle.diagnostics(sp, want)
     want2 = oracle.run(sp, want, g, 1, mode=oracle.MODE_SKIP_INERT)
+    want3 = oracle.run(sp, want2, g, 3, mode=oracle.MODE_SKIP_INERT)
     want_gen = oracle.synth_particles(777, seed=11, pos_extent=20.0)
 
     for rank in range(world):
         r = np.load(tmp_path / f"rank{rank}.npz")
         assert r["full"].tobytes() == want.tobytes()          # byte-identical to the unsharded run
         assert r["full2"].tobytes() == want2.tobytes()
+        assert r["full3"].tobytes() == want3.tobytes()
         assert r["gen"].tobytes() == want_gen.tobytes()       # global indices seed the generator
         assert int(r["count"]) == 1001
         assert abs(float(r["ke"]) - want_diag["kinetic_energy"]) <= 1e-12 * want_diag["kinetic_energy"]
