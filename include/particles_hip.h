@@ -392,8 +392,16 @@ int pcl_step_timing_read(pcl_compute* h, float* elapsed_ms, int32_t* kinds,
 int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks,
                         uint32_t* block_threads, uint32_t* particles_per_lane);
 
-/* Tuning knobs of the streaming kernel (0 keeps the built-in default):
- * grid_blocks caps the persistent grid; variant selects a code variant. */
+/* Tuning knobs for measurements (0 keeps the built-in defaults; results never
+ * depend on them).  grid_blocks caps the grid of the streaming kernel (the
+ * blocks then stride over the tiles).  variant is a bit set:
+ *   0x1      plain instead of non-temporal access to the particle arrays
+ *   0x2      never stage the field in LDS
+ *   0x8      separate counting pass instead of the counting step
+ *   0xF0     log2 of the cells per sort tile (default 8 = 16 x 16 cells)
+ *   0xF000   point of the refresh interval the tile order aims at, in tenths (default 5)
+ *   0x10000  cut-off cells of the binned pair term: one-cell reach only
+ *   0x20000  cut-off cells: at most 20 per axis */
 int pcl_set_tuning(pcl_compute* h, uint32_t grid_blocks, uint32_t variant);
 
 #ifdef __cplusplus
