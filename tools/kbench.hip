@@ -336,10 +336,10 @@ int main(int argc, char** argv)
     if (set == 8) {
         // sorted particles (16x16-cell tiles), block 512: cache-policy bits of the particle-array loads
         const unsigned tile_cells = 16;
-        auto run_spol = [&](auto kernel, const char* name) {
+        auto run_spol = [&](auto kernel, const char* name, unsigned groups_per_lane = 1) {
             hipLaunchKernelGGL(generate_sorted_kernel, dim3(4096), dim3(256), 0, 0, c.s0, c.ty, c.n, side, tile_cells, r);
             CK(hipDeviceSynchronize());
-            const unsigned grid = (unsigned)(c.n / 4ull / 512);
+            const unsigned grid = (unsigned)(c.n / 4ull / 512 / groups_per_lane);
             float total = 0;
             for (int k = 0; k < 8; ++k) {
                 StreamArgs& a = (k & 1) ? c.bwd : c.fwd;
@@ -365,6 +365,7 @@ int main(int argc, char** argv)
         run_spol(variant_kernel<1, true, true, false, true, 512, -1, false, 18>, "buffer_load sc1 nt");
         run_spol(variant_kernel<1, true, true, false, true, 512, -1, false, 17>, "buffer_load sc0 sc1");
         run_spol(variant_kernel<1, true, true, false, true, 512, -1, false, 19>, "buffer_load sc0 sc1 nt");
+        run_spol(variant_kernel<2, true, true, false, true, 512, -1, false, 2>, "buffer_load nt, 8 particles/lane", 2);
     }
     if (set == 2) {
         const unsigned tile_cells = argc > 6 ? atoi(argv[6]) : 16;
