@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--field", type=int, nargs=3, default=(1024, 1024, 1), metavar=("NX", "NY", "NZ"))
     ap.add_argument("--pos-extent", type=float, default=2.0 * RADIUS,
                     help="positions are pos_extent*(u-0.5); 20 = whole cube, 2 = the reference's cluster")
+    ap.add_argument("--vel-extent", type=float, default=10.0,
+                    help="initial velocities are vel_extent*(u-0.5) per axis (10: about 4 field cells per step)")
     ap.add_argument("--diagnostics", choices=("on", "off"), default="off",
                     help="fuse count/kinetic-energy/bounds into the step and all-reduce them per step")
     ap.add_argument("--seed", type=int, default=12345)
@@ -162,7 +164,7 @@ def main():
     # every rank fills its own index range with the seeded scene on the device.
     field_host = swirl_field(*dims, RADIUS, args.seed) if rank == 0 else None
     sc = pa.ShardedCompute.new(None, field_host, n_total=n_local * world, seed=args.seed,
-                               pos_extent=args.pos_extent, vel_extent=10.0, device=local_rank,
+                               pos_extent=args.pos_extent, vel_extent=args.vel_extent, device=local_rank,
                                force_collectives=args.force_collectives)
     assert sc.num_local_particles == n_local
     c = sc.local
@@ -267,6 +269,7 @@ def main():
                 "particles_per_gpu": n_local,
                 "field_dims": list(dims),
                 "pos_extent": args.pos_extent,
+                "vel_extent": args.vel_extent,
                 "diagnostics_per_step": diag_on,
                 "field_edits_per_step": bool(args.edits),
                 "reorder_interval": args.reorder_interval,
@@ -281,7 +284,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(n_local, dims, args.pos_extent),
+                "traffic": measured_traffic(n_local, dims, args.pos_extent) if args.vel_extent == 10.0 else None,
                 "bytes_per_particle_step": BYTES_PER_PARTICLE_STEP,
                 "kernel": {1: "step_stream_kernel", 2: "step_pairs_kernel"}.get(kernel, "none"),
                 "kernel_ms": kernel_ms,
