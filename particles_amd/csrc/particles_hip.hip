@@ -66,6 +66,7 @@ constexpr size_t kStagingRecords = size_t(1) << 22;  // AoS staging chunk: 4 Mi 
 constexpr uint32_t kLdsFieldMaxBytes = 64u * 1024u;  // fields up to this size are staged in LDS
 constexpr int kAutoReorderInterval = 12;               // steps between refreshes of the tile order
 constexpr size_t kPairWideMinParticles = size_t(1) << 18;   // below: the sort over many cells costs more than the sweep saves
+constexpr size_t kHistEntries = (size_t)pcl::kMaxReorderBins * pcl::kCursorGroups;   // counters (and cursors) in d_hist
 constexpr uint32_t kPairMaxCellsPerAxis = 64;          // cut-off cells per axis (beyond 20: counters in global memory)
 constexpr int kAutoReorderMaxInterval = 96;           // automatic pacing never waits longer than this
 constexpr size_t kAutoReorderMinFieldBytes = 64u * 1024u;        // smaller fields are staged in LDS instead
@@ -102,7 +103,7 @@ struct pcl_compute {
     int orig_cur = 0;
     uint32_t* slot_of = nullptr;       // inverse of orig, built on demand
     bool slot_of_valid = false;
-    uint32_t* d_hist = nullptr;        // kMaxReorderBins counters + kMaxReorderBins cursors
+    uint32_t* d_hist = nullptr;        // kMaxReorderBins * kCursorGroups counters, then as many cursors
     size_t reorder_capacity = 0;
     uint64_t steps_since_sort = 0;
     bool hist_valid = false;           // d_hist counts the tile keys of state[cur] (left by a counting step)
@@ -447,7 +448,7 @@ int reserve_reorder(pcl_compute* h)
 {
     if (h->reorder_capacity >= h->capacity && h->d_hist) return PCL_OK;
     PCL_HIP_TRY(hipStreamSynchronize(h->stream));
-    if (!h->d_hist) PCL_HIP_TRY(hipMalloc((void**)&h->d_hist, 2 * pcl::kMaxReorderBins * sizeof(uint32_t)));
+    if (!h->d_hist) PCL_HIP_TRY(hipMalloc((void**)&h->d_hist, 2 * kHistEntries * sizeof(uint32_t)));
     if (h->ty_buf[1]) (void)hipFree(h->ty_buf[1]);
     h->ty_buf[1] = nullptr;
     for (int b = 0; b < 2; ++b) {
@@ -463,14 +464,15 @@ int reserve_reorder(pcl_compute* h)
 
 // Histogram of the tile keys of the current positions into d_hist (separate
 // pass; a preceding counting step leaves the same histogram for free).
-int reorder_count(pcl_compute* h, const pcl::StepUniforms& U, const pcl::TileMap& T)
+int reorder_count(pcl_compute* h, const pcl::StepUniforms& U, const pcl::TileMap& T, uint32_t groups)
 {
     uint32_t* hist = h->d_hist;
-    PCL_HIP_TRY(hipMemsetAsync(hist, 0, T.n_bins * sizeof(uint32_t), h->stream));
-    const uint32_t count_grid = (uint32_t)std::min<size_t>(stream_tiles(h->n), (size_t)h->num_cus * 8);
-    hipLaunchKernelGGL(pcl::reorder_count_kernel, dim3(count_grid), dim3(pcl::kStreamThreads),
+    PCL_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)T.n_bins * groups * sizeof(uint32_t), h->stream));
+    const size_t tiles = stream_tiles(h->n);   // one tile per block: the counter group is the tile's residue
+    PCL_REQUIRE(tiles <= 0x7FFFFFFFu, "too many particles to reorder");
+    hipLaunchKernelGGL(pcl::reorder_count_kernel, dim3((uint32_t)tiles), dim3(pcl::kStreamThreads),
                        (size_t)T.n_bins * sizeof(uint32_t), h->stream, soa_of(h, h->cur), (unsigned long long)h->n,
-                       U, T, hist);
+                       U, T, hist, groups);
     PCL_HIP_TRY(hipGetLastError());
     return PCL_OK;
 }
@@ -485,6 +487,8 @@ void reorder_args(const pcl_compute* h, pcl::ReorderArgs* a)
     a->src_orig = h->sorted ? h->orig[h->orig_cur] : nullptr;
     a->dst_orig = h->orig[h->sorted ? (h->orig_cur ^ 1) : 0];
     a->cursor = nullptr;
+    a->groups = 1;
+    a->n_tiles = 0;
     a->n = h->n;
 }
 
@@ -520,7 +524,7 @@ int wide_sort(pcl_compute* h, const pcl::StepUniforms& U, const pcl::TileMap& C,
     PCL_HIP_TRY(hipGetLastError());
     // the extra zero entry makes the scan leave the total, n, in start[n_bins]
     hipLaunchKernelGGL(pcl::reorder_scan_kernel, dim3(1), dim3(1024), 0, h->stream, (const uint32_t*)hist,
-                       (uint32_t)entries, start);
+                       (uint32_t)entries, 1u, start);
     PCL_HIP_TRY(hipGetLastError());
     pcl::ReorderArgs ra;
     reorder_args(h, &ra);
@@ -533,15 +537,17 @@ int wide_sort(pcl_compute* h, const pcl::StepUniforms& U, const pcl::TileMap& C,
 
 // Exclusive scan of d_hist into the cursors and the argument block of a
 // scatter from state[cur] into state[cur ^ 1].
-int reorder_prepare(pcl_compute* h, const pcl::TileMap& T, pcl::ReorderArgs* a, uint32_t* grid)
+int reorder_prepare(pcl_compute* h, const pcl::TileMap& T, uint32_t groups, pcl::ReorderArgs* a, uint32_t* grid)
 {
     uint32_t* hist = h->d_hist;
-    uint32_t* cursor = h->d_hist + pcl::kMaxReorderBins;
-    hipLaunchKernelGGL(pcl::reorder_scan_kernel, dim3(1), dim3(1024), 0, h->stream, hist, T.n_bins, cursor);
+    uint32_t* cursor = h->d_hist + kHistEntries;
+    hipLaunchKernelGGL(pcl::reorder_scan_kernel, dim3(1), dim3(1024), 0, h->stream, (const uint32_t*)hist, T.n_bins, groups, cursor);
     PCL_HIP_TRY(hipGetLastError());
     reorder_args(h, a);
     a->cursor = cursor;
+    a->groups = groups;
     const size_t full_tiles = (h->n / 4 + pcl::kStreamThreads - 1) / pcl::kStreamThreads;
+    a->n_tiles = (uint32_t)std::min<size_t>(full_tiles, 0x7FFFFFFFu);
     const size_t g = full_tiles + ((h->n % 4) ? 1 : 0);   // one extra block carries the ragged tail
     PCL_REQUIRE(g >= 1 && g <= 0x7FFFFFFFu, "too many particles to reorder");
     *grid = (uint32_t)g;
@@ -568,10 +574,10 @@ int do_reorder(pcl_compute* h)
     if (int rc = reserve_reorder(h)) return rc;
     const pcl::TileMap T = make_tile_map(h->params, effective_reorder_interval(h), tile_log2(h), tile_aim(h));
     const pcl::StepUniforms U = uniforms_of(h);
-    if (int rc = reorder_count(h, U, T)) return rc;
+    if (int rc = reorder_count(h, U, T, pcl::kCursorGroups)) return rc;
     pcl::ReorderArgs a;
     uint32_t grid = 0;
-    if (int rc = reorder_prepare(h, T, &a, &grid)) return rc;
+    if (int rc = reorder_prepare(h, T, pcl::kCursorGroups, &a, &grid)) return rc;
     hipLaunchKernelGGL(pcl::reorder_scatter_kernel, dim3(grid), dim3(pcl::kStreamThreads),
                        pcl::scatter_lds_bytes(T.n_bins), h->stream, a, U, T);
     PCL_HIP_TRY(hipGetLastError());
@@ -713,9 +719,9 @@ int do_step_impl(pcl_compute* h, int* kind)
             // Update and scatter into tile order in one pass.
             if (int rc = reserve_reorder(h)) return rc;
             if (!h->hist_valid)
-                if (int rc = reorder_count(h, U, T)) return rc;
+                if (int rc = reorder_count(h, U, T, pcl::kCursorGroups)) return rc;
             pcl::StepScatterArgs sa;
-            if (int rc = reorder_prepare(h, T, &sa.r, &grid)) return rc;
+            if (int rc = reorder_prepare(h, T, pcl::kCursorGroups, &sa.r, &grid)) return rc;
             if (h->step_diag)
                 if (int rc = reserve_partials(h, grid)) return rc;
             sa.field = h->field;
@@ -742,7 +748,11 @@ int do_step_impl(pcl_compute* h, int* kind)
                 // One tile per block here too: blocks dispatched together then work on
                 // neighbouring tiles, which is what keeps the field fetches cache-resident
                 // (a persistent grid striding over the array measured 15 % slower).
-                PCL_HIP_TRY(hipMemsetAsync(h->d_hist, 0, T.n_bins * sizeof(uint32_t), h->stream));
+                PCL_HIP_TRY(hipMemsetAsync(h->d_hist, 0, (size_t)T.n_bins * pcl::kCursorGroups * sizeof(uint32_t), h->stream));
+                // one tile per block whatever the grid cap says: the counter group is the tile's residue
+                const size_t tiles = stream_tiles(h->n);
+                PCL_REQUIRE(tiles <= 0x7FFFFFFFu, "too many particles for one launch");
+                grid = (uint32_t)tiles;
                 if (!h->d_runs) {
                     PCL_HIP_TRY(hipMalloc((void**)&h->d_runs, pcl::kRunSlots * sizeof(uint32_t)));
                     PCL_HIP_TRY(hipHostMalloc((void**)&h->h_runs, pcl::kRunSlots * sizeof(uint32_t), hipHostMallocDefault));
@@ -760,6 +770,7 @@ int do_step_impl(pcl_compute* h, int* kind)
             a.n = h->n;
             a.partials = h->d_partials;
             a.hist = h->d_hist;
+            a.hist_groups = pcl::kCursorGroups;
             a.runs = (count && !h->runs_pending) ? h->d_runs : nullptr;
             const bool lds = use_lds_field(h);
             a.lds_cells = lds ? (uint32_t)h->n_cells : 0u;
@@ -824,14 +835,14 @@ int do_step_impl(pcl_compute* h, int* kind)
             if (int rc = wide_sort(h, U, C, &start)) return rc;
             bin_end = start + 1;
         } else {
-            if (int rc = reorder_count(h, U, C)) return rc;
+            if (int rc = reorder_count(h, U, C, 1)) return rc;   // one cursor per cell: the sweep needs each cell's end
             pcl::ReorderArgs ra;
             uint32_t sgrid = 0;
-            if (int rc = reorder_prepare(h, C, &ra, &sgrid)) return rc;
+            if (int rc = reorder_prepare(h, C, 1, &ra, &sgrid)) return rc;
             hipLaunchKernelGGL(pcl::reorder_scatter_kernel, dim3(sgrid), dim3(pcl::kStreamThreads),
                                pcl::scatter_lds_bytes(C.n_bins), h->stream, ra, U, C);
             PCL_HIP_TRY(hipGetLastError());
-            bin_end = h->d_hist + pcl::kMaxReorderBins;   // the cursors after the scatter
+            bin_end = h->d_hist + kHistEntries;   // the cursors after the scatter
         }
         reorder_commit(h);
         h->steps_since_sort = 0;

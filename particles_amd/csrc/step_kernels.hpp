@@ -321,7 +321,8 @@ struct StreamArgs {
     unsigned long long n;
     DiagPartial* partials;  // one per block when DIAG
     uint32_t lds_cells;     // cells staged in LDS when FIELD_LDS
-    uint32_t* hist;         // global tile histogram when COUNT
+    uint32_t* hist;         // global tile histogram when COUNT: counter of bin b for tile t is hist[(t % hist_groups) * n_bins + b]
+    uint32_t hist_groups;
     uint32_t* runs;         // when COUNT: total over blocks of the bins each block touched (may be null)
 };
 
@@ -479,10 +480,12 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_kernel(StreamArgs 
 
     if (COUNT) {
         __syncthreads();
+        // one tile per block in a counting launch; the ragged tail (block 0) counts with tile 0
+        const uint32_t count_group = blockIdx.x % a.hist_groups;
         uint32_t touched = 0u;
         for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) {
             const uint32_t c = lds_hist[b];
-            if (c) { atomicAdd(&a.hist[b], c); ++touched; }
+            if (c) { atomicAdd(&a.hist[count_group * T.n_bins + b], c); ++touched; }
         }
         // How many bins this block's particles fall into: 1-2 while the order is intact, more
         // the further they have drifted.  The host reads the total to pace the refreshes
