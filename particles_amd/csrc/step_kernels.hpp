@@ -479,7 +479,7 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_kernel(StreamArgs 
     }
 
     if (COUNT) {
-        __syncthreads();
+        lds_barrier();   // LDS counters only: no need to drain the stores first
         // one tile per block in a counting launch; the ragged tail (block 0) counts with tile 0
         const uint32_t count_group = blockIdx.x % a.hist_groups;
         uint32_t touched = 0u;
