@@ -145,6 +145,91 @@ __global__ __launch_bounds__(256) void copy1_kernel(const f32x4* __restrict__ s,
     }
 }
 
+// Persistent blocks with the next tile's loads in flight while the current tile is updated:
+// per iteration [field fetches of tile i] [array loads of tile i + grid] wait for the fetches,
+// update, [stores of tile i].  vmcnt retires in issue order, so the fetches are issued before the
+// prefetch and waiting for them leaves the prefetch in flight.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void pipelined_kernel(StreamArgs a, StepUniforms U)
+{
+    const unsigned long long n_tiles = a.n / 4ull / BLOCK;   // n is a multiple of 4 * BLOCK here
+    const uint32_t lane16 = threadIdx.x * 16u;
+    unsigned long long t = blockIdx.x;
+    if (t >= n_tiles) return;
+    f32x4 C[6];
+    uint32_t ct;
+    {
+        const unsigned long long g0 = t * BLOCK;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) C[k] = tile_load4(tile_rsrc(a.src[k] + g0 * 4ull, BLOCK * 16u), lane16);
+        ct = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc(a.ty + g0 * 4ull, BLOCK * 4u), (int)(threadIdx.x * 4u), 0, 2);
+    }
+    for (;;) {
+        f32x4 F[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) F[k] = a.field[cell_index(U, C[0][k], C[1][k], C[2][k])];
+        const unsigned long long tn = t + gridDim.x;
+        const bool more = tn < n_tiles;
+        f32x4 N[6];
+        uint32_t nt = 0u;
+        {
+            // unconditional (the last iteration reloads its own tile) so that the wait counts stay exact
+            const unsigned long long g0 = (more ? tn : t) * BLOCK;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) N[k] = tile_load4(tile_rsrc(a.src[k] + g0 * 4ull, BLOCK * 16u), lane16);
+            nt = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc(a.ty + g0 * 4ull, BLOCK * 4u), (int)(threadIdx.x * 4u), 0, 2);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float m = mass_of(U, (ct >> (8 * k)) & 0xFFu);
+            float x = C[0][k], y = C[1][k], z = C[2][k], vx = C[3][k], vy = C[4][k], vz = C[5][k];
+            integrate(U, F[k].x, F[k].y, F[k].z, m, 0.0f, 0.0f, 0.0f, x, y, z, vx, vy, vz);
+            C[0][k] = x; C[1][k] = y; C[2][k] = z; C[3][k] = vx; C[4][k] = vy; C[5][k] = vz;
+        }
+        {
+            const unsigned long long g0 = t * BLOCK;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) tile_store4(tile_rsrc(a.dst[k] + g0 * 4ull, BLOCK * 16u), lane16, C[k]);
+        }
+        if (!more) break;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) C[k] = N[k];
+        ct = nt;
+        t = tn;
+    }
+}
+
+// Two particles per lane (8-byte accesses): half the bytes in flight per wave.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void half_kernel(StreamArgs a, StepUniforms U)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const unsigned long long p0 = (unsigned long long)blockIdx.x * BLOCK * 2ull;   // n is a multiple of 2 * BLOCK here
+    const uint32_t lane8 = threadIdx.x * 8u;
+    f32x2 V[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        V[k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(tile_rsrc(a.src[k] + p0, BLOCK * 8u), (int)lane8, 0, 2));
+    }
+    const uint32_t t2 = __builtin_amdgcn_raw_buffer_load_b16(tile_rsrc(a.ty + p0, BLOCK * 2u), (int)(threadIdx.x * 2u), 0, 2);
+    f32x4 F[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) F[k] = a.field[cell_index(U, V[0][k], V[1][k], V[2][k])];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float m = mass_of(U, (t2 >> (8 * k)) & 0xFFu);
+        float x = V[0][k], y = V[1][k], z = V[2][k], vx = V[3][k], vy = V[4][k], vz = V[5][k];
+        integrate(U, F[k].x, F[k].y, F[k].z, m, 0.0f, 0.0f, 0.0f, x, y, z, vx, vy, vz);
+        V[0][k] = x; V[1][k] = y; V[2][k] = z; V[3][k] = vx; V[4][k] = vy; V[5][k] = vz;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, V[k]), tile_rsrc(a.dst[k] + p0, BLOCK * 8u), (int)lane8, 0, 2);
+    }
+}
+
 // Particles whose memory order follows the field's tile order: particle i sits
 // uniformly inside tile (i * n_tiles / n) of tile_cells x tile_cells cells,
 // tiles enumerated x-major (emulates a cell-sorted particle set).
@@ -366,6 +451,52 @@ int main(int argc, char** argv)
         run_spol(variant_kernel<1, true, true, false, true, 512, -1, false, 17>, "buffer_load sc0 sc1");
         run_spol(variant_kernel<1, true, true, false, true, 512, -1, false, 19>, "buffer_load sc0 sc1 nt");
         run_spol(variant_kernel<2, true, true, false, true, 512, -1, false, 2>, "buffer_load nt, 8 particles/lane", 2);
+    }
+    if (set == 9) {
+        // sorted particles (16x16-cell tiles): the library kernel (one tile per block) against
+        // persistent blocks that keep the next tile's loads in flight
+        const unsigned tile_cells = side >= 16 ? 16 : side;
+        auto run9 = [&](auto launch, const char* name) {
+            hipLaunchKernelGGL(generate_sorted_kernel, dim3(4096), dim3(256), 0, 0, c.s0, c.ty, c.n, side, tile_cells, r);
+            CK(hipDeviceSynchronize());
+            float total = 0;
+            for (int k = 0; k < 8; ++k) {
+                StreamArgs& a = (k & 1) ? c.bwd : c.fwd;
+                CK(hipEventRecord(c.e0));
+                launch(a);
+                CK(hipEventRecord(c.e1));
+                CK(hipEventSynchronize(c.e1));
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, c.e0, c.e1));
+                if (k >= 2) total += ms;
+            }
+            CK(hipGetLastError());
+            printf("%-44s steps 2..7 after the sort: %8.4f ms average  %7.1f GB/s\n", name, total / 6, c.n * 49.0 / (total / 6) / 1e6);
+            fflush(stdout);
+        };
+        TileMap T{};
+        c.fwd.hist = c.bwd.hist = nullptr; c.fwd.hist_groups = c.bwd.hist_groups = 1; c.fwd.runs = c.bwd.runs = nullptr;
+        run9([&](StreamArgs& a) {
+            hipLaunchKernelGGL((step_stream_kernel<false, true, false, false>), dim3((unsigned)(c.n / 4 / kStreamThreads)), dim3(kStreamThreads), 0, 0, a, c.U, T);
+        }, "library kernel, one tile per block");
+        for (unsigned per_cu : {2u, 3u, 4u}) {
+            char name[96];
+            snprintf(name, sizeof name, "pipelined, block 512, %u blocks per CU", per_cu);
+            run9([&](StreamArgs& a) { hipLaunchKernelGGL((pipelined_kernel<512>), dim3(256 * per_cu), dim3(512), 0, 0, a, c.U); }, name);
+        }
+        for (unsigned per_cu : {4u, 6u, 8u}) {
+            char name[96];
+            snprintf(name, sizeof name, "pipelined, block 256, %u blocks per CU", per_cu);
+            run9([&](StreamArgs& a) { hipLaunchKernelGGL((pipelined_kernel<256>), dim3(256 * per_cu), dim3(256), 0, 0, a, c.U); }, name);
+        }
+        run9([&](StreamArgs& a) { hipLaunchKernelGGL((half_kernel<512>), dim3((unsigned)(c.n / 2 / 512)), dim3(512), 0, 0, a, c.U); }, "two particles per lane, block 512");
+        run9([&](StreamArgs& a) { hipLaunchKernelGGL((half_kernel<1024>), dim3((unsigned)(c.n / 2 / 1024)), dim3(1024), 0, 0, a, c.U); }, "two particles per lane, block 1024");
+        run9([&](StreamArgs& a) { hipLaunchKernelGGL((half_kernel<256>), dim3((unsigned)(c.n / 2 / 256)), dim3(256), 0, 0, a, c.U); }, "two particles per lane, block 256");
+        for (unsigned per_cu : {8u, 12u, 16u}) {
+            char name[96];
+            snprintf(name, sizeof name, "pipelined, block 128, %u blocks per CU", per_cu);
+            run9([&](StreamArgs& a) { hipLaunchKernelGGL((pipelined_kernel<128>), dim3(256 * per_cu), dim3(128), 0, 0, a, c.U); }, name);
+        }
     }
     if (set == 2) {
         const unsigned tile_cells = argc > 6 ? atoi(argv[6]) : 16;
