@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -228,6 +229,94 @@ __global__ __launch_bounds__(BLOCK) void half_kernel(StreamArgs a, StepUniforms 
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, V[k]), tile_rsrc(a.dst[k] + p0, BLOCK * 8u), (int)lane8, 0, 2);
     }
+}
+
+// The library kernel's access shape with the cache-policy bits of the six stores (and loads) as
+// template parameters (buffer aux: 1 = sc0, 2 = nt, 16 = sc1).
+template <int LDPOL, int STPOL>
+__global__ __launch_bounds__(512) void policy_kernel(StreamArgs a, StepUniforms U)
+{
+    const unsigned long long g0 = (unsigned long long)blockIdx.x * 512ull;   // n is a multiple of 2048 here
+    const uint32_t lane16 = threadIdx.x * 16u;
+    f32x4 V[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        V[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tile_rsrc(a.src[k] + g0 * 4ull, 512u * 16u), (int)lane16, 0, LDPOL));
+    const uint32_t t4 = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc(a.ty + g0 * 4ull, 512u * 4u), (int)(threadIdx.x * 4u), 0, LDPOL);
+    f32x4 F[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) F[k] = a.field[cell_index(U, V[0][k], V[1][k], V[2][k])];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float m = mass_of(U, (t4 >> (8 * k)) & 0xFFu);
+        float x = V[0][k], y = V[1][k], z = V[2][k], vx = V[3][k], vy = V[4][k], vz = V[5][k];
+        integrate(U, F[k].x, F[k].y, F[k].z, m, 0.0f, 0.0f, 0.0f, x, y, z, vx, vy, vz);
+        V[0][k] = x; V[1][k] = y; V[2][k] = z; V[3][k] = vx; V[4][k] = vy; V[5][k] = vz;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, V[k]), tile_rsrc(a.dst[k] + g0 * 4ull, 512u * 16u), (int)lane16, 0, STPOL);
+}
+
+// The library kernel's work with the order of its memory requests and waits spelled out
+// (sched_barrier keeps the compiler from moving instructions across the marked points):
+//   MODE 0  as the compiler schedules it (the library kernel's shape)
+//   MODE 1  all seven array loads returned before the first index is computed, four fetches back to back
+//   MODE 2  positions returned -> four indices -> four fetches back to back (velocities still in flight)
+//   MODE 3  positions loaded and returned, four fetches issued, THEN velocities and types loaded
+//   MODE 4  as 2 with the masses pinned in scalar registers (no indexed load of the mass)
+//   MODE 5  as 1 with pinned masses
+// PIN (modes 4, 5) and the 16-byte fetch are the only code differences besides the order.
+template <int MODE, int SLEEP_MID = 0, int SLEEP_END = 0>
+__global__ __launch_bounds__(512) void order_kernel(StreamArgs a, StepUniforms U)
+{
+    const unsigned long long g0 = (unsigned long long)blockIdx.x * 512ull;   // n is a multiple of 2048 here
+    const uint32_t lane16 = threadIdx.x * 16u;
+    f32x4 V[6];
+    uint32_t t4;
+    auto ld = [&](int k) { V[k] = tile_load4(tile_rsrc(a.src[k] + g0 * 4ull, 512u * 16u), lane16); };
+    auto ldt = [&]() { t4 = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc(a.ty + g0 * 4ull, 512u * 4u), (int)(threadIdx.x * 4u), 0, 2); };
+    ld(0); ld(1); ld(2);
+    if (MODE != 3) { ld(3); ld(4); ld(5); ldt(); }
+    if (MODE == 1 || MODE == 5) { __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_sched_barrier(0); }
+    f32x4 F[4];
+    if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) F[k] = a.field[cell_index(U, V[0][k], V[1][k], V[2][k])];
+    } else {
+        uint32_t c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k] = cell_index(U, V[0][k], V[1][k], V[2][k]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) F[k] = a.field[c[k]];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (MODE == 3) { ld(3); ld(4); ld(5); ldt(); __builtin_amdgcn_sched_barrier(0); }
+    if (SLEEP_MID) { __builtin_amdgcn_s_sleep(SLEEP_MID); __builtin_amdgcn_sched_barrier(0); }
+    float m0 = U.mass[0], m1 = U.mass[1], m2 = U.mass[2], m3 = U.mass[3], m4 = U.mass[4];
+    if (MODE >= 4) asm("" : "+s"(m0), "+s"(m1), "+s"(m2), "+s"(m3), "+s"(m4));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t ty = (t4 >> (8 * k)) & 0xFFu;
+        float m = m4;
+        m = ty == 3u ? m3 : m;
+        m = ty == 2u ? m2 : m;
+        m = ty == 1u ? m1 : m;
+        m = ty == 0u ? m0 : m;
+        float x = V[0][k], y = V[1][k], z = V[2][k], vx = V[3][k], vy = V[4][k], vz = V[5][k];
+        integrate(U, F[k].x, F[k].y, F[k].z, m, 0.0f, 0.0f, 0.0f, x, y, z, vx, vy, vz);
+        V[0][k] = x; V[1][k] = y; V[2][k] = z; V[3][k] = vx; V[4][k] = vy; V[5][k] = vz;
+    }
+    if (SLEEP_END) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < SLEEP_END / 100; ++q) __builtin_amdgcn_s_sleep(100);
+        if (SLEEP_END % 100) __builtin_amdgcn_s_sleep(SLEEP_END % 100);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) tile_store4(tile_rsrc(a.dst[k] + g0 * 4ull, 512u * 16u), lane16, V[k]);
 }
 
 // Particles whose memory order follows the field's tile order: particle i sits
@@ -496,6 +585,74 @@ int main(int argc, char** argv)
             char name[96];
             snprintf(name, sizeof name, "pipelined, block 128, %u blocks per CU", per_cu);
             run9([&](StreamArgs& a) { hipLaunchKernelGGL((pipelined_kernel<128>), dim3(256 * per_cu), dim3(128), 0, 0, a, c.U); }, name);
+        }
+    }
+    if (set == 10) {
+        const unsigned tile_cells = side >= 16 ? 16 : side;
+        auto run10 = [&](auto kernel, const char* name) {
+            hipLaunchKernelGGL(generate_sorted_kernel, dim3(4096), dim3(256), 0, 0, c.s0, c.ty, c.n, side, tile_cells, r);
+            CK(hipDeviceSynchronize());
+            float total = 0;
+            for (int k = 0; k < 8; ++k) {
+                StreamArgs& a = (k & 1) ? c.bwd : c.fwd;
+                CK(hipEventRecord(c.e0));
+                hipLaunchKernelGGL(kernel, dim3((unsigned)(c.n / 2048)), dim3(512), 0, 0, a, c.U);
+                CK(hipEventRecord(c.e1));
+                CK(hipEventSynchronize(c.e1));
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, c.e0, c.e1));
+                if (k >= 2) total += ms;
+            }
+            CK(hipGetLastError());
+            printf("%-36s steps 2..7 after the sort: %8.4f ms average  %7.1f GB/s\n", name, total / 6, c.n * 49.0 / (total / 6) / 1e6);
+            fflush(stdout);
+        };
+        run10(policy_kernel<2, 2>, "loads nt, stores nt (library)");
+        run10(policy_kernel<2, 0>, "loads nt, stores plain");
+        run10(policy_kernel<2, 1>, "loads nt, stores sc0");
+        run10(policy_kernel<2, 3>, "loads nt, stores sc0 nt");
+        run10(policy_kernel<2, 16>, "loads nt, stores sc1");
+        run10(policy_kernel<2, 18>, "loads nt, stores sc1 nt");
+        run10(policy_kernel<2, 17>, "loads nt, stores sc0 sc1");
+        run10(policy_kernel<2, 19>, "loads nt, stores sc0 sc1 nt");
+        run10(policy_kernel<0, 2>, "loads plain, stores nt");
+        run10(policy_kernel<2, 2>, "loads nt, stores nt (again)");
+    }
+    if (set == 11) {
+        const unsigned tile_cells = side >= 16 ? 16 : side;
+        TileMap T{};
+        auto run11 = [&](auto kernel, const char* name) {
+            hipLaunchKernelGGL(generate_sorted_kernel, dim3(4096), dim3(256), 0, 0, c.s0, c.ty, c.n, side, tile_cells, r);
+            CK(hipDeviceSynchronize());
+            float total = 0;
+            for (int k = 0; k < 8; ++k) {
+                StreamArgs& a = (k & 1) ? c.bwd : c.fwd;
+                CK(hipEventRecord(c.e0));
+                if constexpr (std::is_same_v<decltype(kernel), decltype(&step_stream_kernel<false, true, false, false>)>)
+                    hipLaunchKernelGGL(kernel, dim3((unsigned)(c.n / 2048)), dim3(512), 0, 0, a, c.U, T);
+                else
+                    hipLaunchKernelGGL(kernel, dim3((unsigned)(c.n / 2048)), dim3(512), 0, 0, a, c.U);
+                CK(hipEventRecord(c.e1));
+                CK(hipEventSynchronize(c.e1));
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, c.e0, c.e1));
+                if (k < 6) total += ms;
+            }
+            CK(hipGetLastError());
+            printf("%-44s steps 0..5 after the sort: %8.4f ms average  %7.1f GB/s\n", name, total / 6, c.n * 49.0 / (total / 6) / 1e6);
+            fflush(stdout);
+        };
+        c.fwd.hist = c.bwd.hist = nullptr; c.fwd.hist_groups = c.bwd.hist_groups = 1; c.fwd.runs = c.bwd.runs = nullptr;
+        for (int rep = 0; rep < 2; ++rep) {
+            run11(step_stream_kernel<false, true, false, false>, "library kernel");
+            run11(order_kernel<2, 0, 0>, "2 positions back, then 4 fetches");
+            run11(order_kernel<2, 0, 50>, "2 + sleep 3200 clk before the stores");
+            run11(order_kernel<2, 0, 100>, "2 + sleep 6400 clk before the stores");
+            run11(order_kernel<2, 0, 200>, "2 + sleep 12800 clk before the stores");
+            run11(order_kernel<2, 0, 400>, "2 + sleep 25600 clk before the stores");
+            run11(order_kernel<2, 0, 800>, "2 + sleep 51200 clk before the stores");
+            run11(order_kernel<2, 100, 0>, "2 + sleep 6400 clk after the fetches");
+            run11(order_kernel<2, 100, 100>, "2 + sleep 6400 clk after the fetches and before the stores");
         }
     }
     if (set == 2) {
