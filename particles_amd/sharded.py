@@ -16,6 +16,10 @@ travels, over ``torch.distributed`` (backend "nccl" is RCCL over xGMI on ROCm):
 * per-step diagnostics — two tiny all-reduces (sum: count, kinetic energy;
   max: max xyz, -min xyz), issued asynchronously so they overlap the next step.
 
+Under a host-memory process group (backend "gloo") the same class drives the
+GPU backend with every collective staged through the host: slower, but it
+needs no RCCL, and several ranks may then share one GPU.
+
 The class mirrors ``Compute`` (src/compute.rs:11-228); ``compute_cls`` is the
 single-GPU backend each rank instantiates for its range.
 """
@@ -88,6 +92,7 @@ class ShardedCompute:
         self._params = SimParams()     # the handle starts with SimParams::new(): all curves zero
         self._pair_active = False
         self._pair_bufs = None
+        self._pair_stage = None
         self._diag_enabled = False
         # Ring of diagnostics records: an all-reduce in flight owns its record
         # until waited for, so consecutive steps use different ones.
@@ -235,10 +240,27 @@ class ShardedCompute:
             self.local.pack_pair_sources_device(send.data_ptr(), cap)
             dist.all_gather_into_tensor(recv, send, group=self.group)
             self.local.step_pairs_gathered(recv.data_ptr(), recv.shape[0])
-        else:
+        elif hasattr(self.local, "pack_pair_sources"):
+            # host-resident backend (the tests' CPU stand-in)
             send.copy_(torch.from_numpy(self.local.pack_pair_sources(cap)))
             dist.all_gather_into_tensor(recv, send, group=self.group)
             self.local.step_pairs_gathered(recv.numpy(), self.rank * cap)
+        else:
+            # GPU backend under a host-memory process group (gloo): the records are staged
+            # through the host on their way to the collective and back
+            dev = torch.device("cuda", self.device)
+            if self._pair_stage is None or self._pair_stage[0].shape[0] != cap:
+                self._pair_stage = (torch.empty((cap, 4), dtype=torch.float32, device=dev),
+                                    torch.empty((cap * self.world_size, 4), dtype=torch.float32, device=dev))
+            send_dev, recv_dev = self._pair_stage
+            self.local.synchronize()             # the previous step may still read recv_dev
+            self.local.pack_pair_sources_device(send_dev.data_ptr(), cap)
+            self.local.synchronize()
+            send.copy_(send_dev)
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+            recv_dev.copy_(recv)
+            torch.cuda.synchronize(dev)
+            self.local.step_pairs_gathered(recv_dev.data_ptr(), recv_dev.shape[0])
 
     def _advance(self, dt=None):
         if self._pair_active and self._collectives and self.n_total > 0:
