@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--edits", action="store_true",
                     help="every step a brush (src/cursor.rs, Shift mode) rewrites the cells within falloff_dist of a "
                          "moving cursor on the device field; rank 0's cursor record is broadcast before the step")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend: nccl is RCCL over xGMI; gloo stages every collective through the host "
+                         "and admits several ranks on one GPU (a rehearsal of the multi-rank path on a one-GPU box)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="use the RCCL broadcast/all-reduce path even with one rank (when started by torch.distributed.run)")
     args = ap.parse_args()
@@ -151,9 +154,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % torch.cuda.device_count()   # one GPU per rank; wraps only in a gloo rehearsal
+    if args.backend == "nccl" and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: RCCL needs one GPU per rank ({torch.cuda.device_count()} visible)")
+    torch.cuda.set_device(device_index)
     if world > 1 or (args.force_collectives and "RANK" in os.environ):
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo")
+    reduce_device = "cuda" if args.backend == "nccl" else "cpu"
 
     dims = tuple(args.field)
     n_cells = dims[0] * dims[1] * dims[2]
@@ -164,7 +174,7 @@ def main():
     # every rank fills its own index range with the seeded scene on the device.
     field_host = swirl_field(*dims, RADIUS, args.seed) if rank == 0 else None
     sc = pa.ShardedCompute.new(None, field_host, n_total=n_local * world, seed=args.seed,
-                               pos_extent=args.pos_extent, vel_extent=args.vel_extent, device=local_rank,
+                               pos_extent=args.pos_extent, vel_extent=args.vel_extent, device=device_index,
                                force_collectives=args.force_collectives)
     assert sc.num_local_particles == n_local
     c = sc.local
@@ -209,6 +219,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     launch_ms, launch_kind = c.step_timing_read()
+    reorders_timed = c.reorder_count - reorders0
     # the dominant kernel: the plain step kernel (streaming or pair), without the launches that
     # also count / scatter for the order refresh
     plain = launch_ms[(launch_kind == 1) | (launch_kind == 2)]
@@ -219,7 +230,7 @@ def main():
                                (3, "step_stream_kernel+count"), (4, "step_scatter_kernel"))}
 
     if dist.is_initialized():
-        t = torch.tensor([elapsed, kernel_ms, region_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, kernel_ms, region_ms], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms, region_ms = float(t[0]), float(t[1]), float(t[2])
 
@@ -233,7 +244,7 @@ def main():
         fused_ms = c.timer_stop() / args.fused_steps
         fence()
         if dist.is_initialized():
-            t = torch.tensor([fused_ms], dtype=torch.float64, device="cuda")
+            t = torch.tensor([fused_ms], dtype=torch.float64, device=reduce_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             fused_ms = float(t[0])
         fused = {"steps": args.fused_steps, "ms_per_step": fused_ms,
@@ -273,8 +284,9 @@ def main():
                 "diagnostics_per_step": diag_on,
                 "field_edits_per_step": bool(args.edits),
                 "reorder_interval": args.reorder_interval,
-                "reorder_passes_in_timed_region": c.reorder_count - reorders0,
-                "parallelism": f"particle-sharded x{world}, field replicated by RCCL broadcast",
+                "reorder_passes_in_timed_region": reorders_timed,
+                "parallelism": f"particle-sharded x{world}, field replicated by "
+                               + ("RCCL broadcast" if args.backend == "nccl" else "gloo broadcast (host-staged rehearsal)"),
                 "kernel": {1: "step_stream_kernel", 2: "step_pairs_kernel"}.get(kernel, "none"),
                 "launch": geometry,
             },
