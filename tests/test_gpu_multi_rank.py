@@ -3,7 +3,7 @@ library on device 0 and its own index range, talking over a host-memory
 process group (gloo; RCCL does not admit several ranks on one device).  The
 whole sharded path with the real backend and more than one rank: field
 replication from rank 0, range ownership, device-generated shards seeded by
-global index, the brush replicated on every rank's field, diagnostics
+global index, the brush replicated on every rank's field, field patches, diagnostics
 all-reduce, and the pair term's all-gather — each compared with the unsharded
 CPU oracle, bit for bit."""
 import os
@@ -20,6 +20,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 WORLD = 3
 N = 30011            # ranges of 10003, 10004, 10004
 N_PAIRS = 2501
+PATCH = np.arange(40 * 4, dtype=np.float32).reshape(40, 4) / np.float32(16.0) - np.float32(5.0)
+PATCH_IDX = np.array([9215, 0, 4607], dtype=np.uint32)
 
 
 def _free_port():
@@ -76,6 +78,9 @@ def _worker(rank, world, port, out_dir):
         sc.brush_mouse_down(mode.record((1.0, -2.0, 0.0)) if rank == 0 else None)
         sc.brush_mouse_moved(mode.record((1.5, -1.0, 0.0)) if rank == 0 else None)
         sc.brush_mouse_up()
+        # dirty range and list of cells from rank 0 only
+        sc.patch_force_grid(4000, PATCH if rank == 0 else None)
+        sc.patch_force_grid_indexed(PATCH_IDX if rank == 0 else None, PATCH[:3] if rank == 0 else None)
         sc.compute_n(5)
         stream = sc.gather_particles()
         diag = sc.diagnostics()
@@ -113,6 +118,8 @@ def test_three_ranks_on_one_gpu_match_the_unsharded_oracle(tmp_path, oracle):
     model.brush_mouse_down(mode.record((1.0, -2.0, 0.0)))
     model.brush_mouse_moved(mode.record((1.5, -1.0, 0.0)))
     model.brush_mouse_up()
+    model.patch_force_grid(4000, PATCH)
+    model.patch_force_grid_indexed(PATCH_IDX, PATCH[:3])
     model.step_n(5)
     want_stream = model.read_particles()
     want_diag = model.diagnostics()
