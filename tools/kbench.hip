@@ -629,7 +629,7 @@ int main(int argc, char** argv)
                 StreamArgs& a = (k & 1) ? c.bwd : c.fwd;
                 CK(hipEventRecord(c.e0));
                 if constexpr (std::is_same_v<decltype(kernel), decltype(&step_stream_kernel<false, true, false, false>)>)
-                    hipLaunchKernelGGL(kernel, dim3((unsigned)(c.n / 2048)), dim3(512), 0, 0, a, c.U, T);
+                    hipLaunchKernelGGL(kernel, dim3((unsigned)(c.n / kStreamTile)), dim3(kStreamThreads), 0, 0, a, c.U, T);
                 else
                     hipLaunchKernelGGL(kernel, dim3((unsigned)(c.n / 2048)), dim3(512), 0, 0, a, c.U);
                 CK(hipEventRecord(c.e1));
@@ -724,6 +724,7 @@ int main(int argc, char** argv)
             printf("copy of %d arrays, block %4d: %8.4f ms %8.1f GB/s\n", K, BLOCK, ms, c.n * 8.0 * K / ms / 1e6); \
             fflush(stdout);                                                                                       \
         }
+        RUNK(1, 64) RUNK(6, 64) RUNK(1, 128) RUNK(6, 128)
         RUNK(1, 256) RUNK(2, 256) RUNK(3, 256) RUNK(4, 256) RUNK(6, 256)
         RUNK(1, 512) RUNK(2, 512) RUNK(3, 512) RUNK(6, 512)
         RUNK(1, 1024) RUNK(3, 1024) RUNK(6, 1024)
