@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--grid-blocks", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch-timing", choices=("on", "off"), default="on",
+                    help="off: no per-launch event pairs (the roofline then uses the whole region's time per step)")
     ap.add_argument("--fused-steps", type=int, default=96,
                     help="after the timed region, also time this many steps through pcl_step_n (0: skip)")
     ap.add_argument("--edits", action="store_true",
@@ -210,7 +212,7 @@ def main():
         one_step()
     fence()
     reorders0 = c.reorder_count
-    c.step_timing_begin(args.steps)          # one HIP event pair per launch, on the kernel's stream, no syncs
+    c.step_timing_begin(args.steps if args.launch_timing == "on" else 0)   # one HIP event pair per launch, on the kernel's stream, no syncs
     t0 = time.perf_counter()
     c.timer_start()
     for _ in range(args.steps):

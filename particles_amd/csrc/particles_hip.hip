@@ -1700,7 +1700,8 @@ int pcl_step_timing_begin(pcl_compute* h, size_t max_steps)
     if (int rc = bind(h)) return rc;
     while (h->timing_events.size() < 2 * max_steps) {
         hipEvent_t e = nullptr;
-        PCL_HIP_TRY(hipEventCreate(&e));
+        // timestamps only: no system-scope fence (cache write-back) with every record
+        PCL_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
         h->timing_events.push_back(e);
     }
     h->timing_kinds.assign(max_steps, PCL_STEP_NONE);
