@@ -95,7 +95,14 @@ def _worker(rank, world, port, out_dir):
         for _ in range(3):
             sc.compute()
         pairs = sc.gather_particles()
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), stream=stream, pairs=pairs, field=field,
+        # two particles over three ranks: rank 0's range is empty, it still takes part in everything
+        sc.upload_particles(p[:2])
+        assert sc.num_local_particles == (0, 1, 1)[rank]
+        sc.compute()
+        sparse = sc.gather_particles()
+        sparse_count = sc.diagnostics()["count"]
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), stream=stream, pairs=pairs, field=field, sparse=sparse,
+                 sparse_count=sparse_count,
                  count=diag["count"], ke=diag["kinetic_energy"], pos_max=diag["pos_max"], pos_min=diag["pos_min"],
                  reorders=reorders, kernel=sc.local.last_step_kernel)
         sc.close()
@@ -129,6 +136,9 @@ def test_three_ranks_on_one_gpu_match_the_unsharded_oracle(tmp_path, oracle):
     for _ in range(3):
         model.compute()
     want_pairs = model.read_particles()
+    model.upload_particles(oracle.synth_particles(N_PAIRS, seed=32, pos_extent=6.0, vel_extent=4.0)[:2])
+    model.compute()
+    want_sparse = model.read_particles()
     assert not np.array_equal(want_field, g)                      # the brush did change cells
 
     for rank in range(WORLD):
@@ -136,6 +146,7 @@ def test_three_ranks_on_one_gpu_match_the_unsharded_oracle(tmp_path, oracle):
         assert r["stream"].tobytes() == want_stream.tobytes(), f"rank {rank}: streaming path"
         assert r["field"].tobytes() == want_field.tobytes(), f"rank {rank}: field after the brush"
         assert r["pairs"].tobytes() == want_pairs.tobytes(), f"rank {rank}: pair path"
+        assert r["sparse"].tobytes() == want_sparse.tobytes() and int(r["sparse_count"]) == 2, f"rank {rank}: empty range"
         assert int(r["kernel"]) == pa.KERNEL_PAIRS and int(r["reorders"]) >= 2
         assert int(r["count"]) == N
         assert abs(float(r["ke"]) - want_diag["kinetic_energy"]) <= 1e-12 * want_diag["kinetic_energy"]

@@ -224,3 +224,50 @@ def test_shard_ranges_partition_the_set(n, world):
         assert a[1] == b[0]
     sizes = [b - a for a, b in edges]
     assert max(sizes) - min(sizes) <= 1
+
+
+def _sparse_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    import particles_amd as pa
+    from oracle import oracle as O
+    from oracle_backend import OracleCompute
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sp, particles, grid = _pair_scene(pa, O, 2)     # two particles over three ranks: rank 0 owns none
+        sc = pa.ShardedCompute.new(particles.view(pa.PARTICLE_DTYPE), grid if rank == 0 else None,
+                                   compute_cls=OracleCompute)
+        assert sc.num_local_particles == (0, 1, 1)[rank]
+        sc.enable_step_diagnostics(True)
+        inert = pa.SimParams()
+        inert.delta_t = sp.delta_t
+        sc.update_sim_params(inert)
+        sc.compute()                                     # streaming path with an empty range
+        sc.update_sim_params(sp)
+        sc.compute()                                     # pair path: rank 0 contributes padding only
+        d = sc.diagnostics()
+        np.savez(os.path.join(out_dir, f"sparse_rank{rank}.npz"), full=sc.gather_particles(), count=d["count"],
+                 ke=d["kinetic_energy"])
+        sc.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_more_ranks_than_particles(tmp_path, oracle):
+    """Ranks whose index range is empty take part in every collective."""
+    import particles_amd as pa
+    world = 3
+    mp.spawn(_sparse_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sp, p, g = _pair_scene(pa, oracle, 2)
+    inert = pa.SimParams()
+    inert.delta_t = sp.delta_t
+    want = oracle.run(sp, oracle.run(inert, p, g, 1, mode=oracle.MODE_SKIP_INERT), g, 1)
+    ke = oracle.diagnostics(sp, want)["kinetic_energy"]
+    for rank in range(world):
+        r = np.load(tmp_path / f"sparse_rank{rank}.npz")
+        assert r["full"].tobytes() == want.tobytes()
+        assert int(r["count"]) == 2 and abs(float(r["ke"]) - ke) <= 1e-12 * max(ke, 1e-300)
