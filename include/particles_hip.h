@@ -352,7 +352,8 @@ int pcl_timer_stop(pcl_compute* h, float* elapsed_ms);
  * the per-particle field fetch stays cache-resident for fields larger than an
  * XCD's L2.  Per-particle results are unchanged bit for bit and every read
  * returns caller order.  interval: -1 automatic (default: every 12 steps for
- * fields above 64 KiB and at least 2^20 particles), 0 never, k > 0 every k steps. */
+ * fields above 16 KiB and at least 2^20 particles, except where the field is
+ * staged in LDS: up to 64 KiB with 2^22 to 2^24 particles), 0 never, k > 0 every k steps. */
 int pcl_set_reorder_interval(pcl_compute* h, int interval);
 
 /* The interval currently in force: 0 when the order is not maintained (small

@@ -69,7 +69,11 @@ constexpr size_t kPairWideMinParticles = size_t(1) << 18;   // below: the sort o
 constexpr size_t kHistEntries = (size_t)pcl::kMaxReorderBins * pcl::kCursorGroups;   // counters (and cursors) in d_hist
 constexpr uint32_t kPairMaxCellsPerAxis = 64;          // cut-off cells per axis (beyond 20: counters in global memory)
 constexpr int kAutoReorderMaxInterval = 96;           // automatic pacing never waits longer than this
-constexpr size_t kAutoReorderMinFieldBytes = 64u * 1024u;        // smaller fields are staged in LDS instead
+constexpr size_t kAutoReorderMinFieldBytes = 16u * 1024u;        // up to here the vector L1 holds the field well enough
+// The LDS-staged field needs a persistent grid, and persistent grids stream more slowly than one
+// tile per block once the set is large (2^28 particles, 64 KiB field: 2.60 ms against 2.38 ms per
+// step in tile order; 2^24: 0.173 against 0.167; 2^22: 0.0502 against 0.0506).
+constexpr size_t kLdsFieldMaxParticles = size_t(1) << 24;
 constexpr size_t kAutoReorderMinParticles = size_t(1) << 20;
 constexpr size_t kPairBinnedMinParticles = size_t(1) << 15;  // automatic switch to the cell-binned pair kernel
 // Most steps one launch of step_stream_fused_kernel performs (the kernel is VALU-bound well before).
@@ -306,13 +310,15 @@ size_t stream_tiles(size_t n)
     return std::max<size_t>(1, (groups + pcl::kStreamThreads - 1) / pcl::kStreamThreads);
 }
 
-// Small field and enough tiles per persistent block to amortise the copy:
-// stage the field in LDS (variant bit 1 disables it).
+// Small field, enough tiles per persistent block to amortise the copy, and a set small
+// enough for the persistent grid not to cost more than it saves: stage the field in LDS
+// (variant bit 1 disables it).
 bool use_lds_field(const pcl_compute* h)
 {
     const size_t field_bytes = h->n_cells * sizeof(pcl::f32x4);
     const size_t persistent = (size_t)h->num_cus * 2;
-    return field_bytes <= kLdsFieldMaxBytes && (h->variant & 2u) == 0 && stream_tiles(h->n) >= persistent * 4;
+    return field_bytes <= kLdsFieldMaxBytes && (h->variant & 2u) == 0 && stream_tiles(h->n) >= persistent * 4 &&
+           h->n < kLdsFieldMaxParticles;
 }
 
 // One tile per block, or (LDS-staged field, or an explicit cap) a persistent

@@ -385,7 +385,7 @@ constexpr uint32_t kRunSlots = 256;   // counters of StreamArgs::runs
 template <bool DIAG, bool NT, bool FIELD_LDS, bool COUNT = false>
 __global__ __launch_bounds__(kStreamThreads) void step_stream_kernel(StreamArgs a, StepUniforms U, TileMap T)
 {
-    // Small fields (<= 64 KiB) are staged in LDS once per persistent block;
+    // Small fields (<= 64 KiB; the host decides when it pays) are staged in LDS once per persistent block;
     // larger ones are fetched through L2 / Infinity Cache.
     extern __shared__ __attribute__((aligned(16))) f32x4 lds_field[];
     uint32_t* lds_hist = reinterpret_cast<uint32_t*>(lds_field);

@@ -191,17 +191,17 @@ def test_invalid_type_rejected():
 
 
 def test_lds_field_path_large_n(oracle):
-    # 10^3 cells = 16 KB: staged in LDS once n is large enough per persistent block
+    # 10^3 cells = 16 KB: staged in LDS by a persistent grid from 2^22 particles on (8 tiles per block)
     sp = pa.SimParams()
     sp.delta_t = DT
     g = sp.new_force_grid_centered().get_force_vectors()
-    n = 1 << 20
+    n = (1 << 22) + 3
     with pa.Compute.new(pa.empty_particles(0), g) as c:
         c.update_sim_params(sp)
-        c.set_tuning(grid_blocks=64)
         c.generate_particles(n, seed=77, pos_extent=20.0, vel_extent=10.0)
         c.compute()
         c.compute()
+        assert c.launch_geometry()["grid_blocks"] == 512 and c.reorder_interval_in_use == 0   # the persistent grid
         got = c.read_particles(n - 5000, 5000)
     p = oracle.synth_particles(5000, seed=77, first_global_index=n - 5000, pos_extent=20.0, vel_extent=10.0)
     want = oracle.run(sp, p, g, 2, mode=oracle.MODE_SKIP_INERT)
