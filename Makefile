@@ -7,14 +7,26 @@ HIPFLAGS  ?= -O3 --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math -fPIC -
 
 LIB       := particles_amd/libparticles_hip.so
 SRC       := particles_amd/csrc/particles_hip.hip
+SORT_SRC  := particles_amd/csrc/pair_sort.hip
+SORT_OBJ  := build/pair_sort.o
 HDRS      := particles_amd/csrc/step_kernels.hpp particles_amd/csrc/reorder_kernels.hpp particles_amd/csrc/brush_kernels.hpp include/particles_hip.h
 
 CPPTEST   := tests/cpp/compute_wrapper_test
 
 all: $(LIB) oracle $(CPPTEST)
 
-$(LIB): $(SRC) $(HDRS)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRC)
+# rocPRIM's radix sort in its own object: it compiles slowly and changes rarely
+$(SORT_OBJ): $(SORT_SRC)
+	mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -Wno-unused-parameter -c -o $@ $(SORT_SRC)
+
+MAIN_OBJ  := build/particles_hip.o
+$(MAIN_OBJ): $(SRC) $(HDRS)
+	mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $(SRC)
+
+$(LIB): $(MAIN_OBJ) $(SORT_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $(MAIN_OBJ) $(SORT_OBJ)
 
 oracle:
 	$(MAKE) -C oracle

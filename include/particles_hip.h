@@ -84,7 +84,12 @@ enum {
     PCL_ERR_INVALID      = -1, /* bad argument (null pointer, size mismatch, ty >= 5, ...) */
     PCL_ERR_HIP          = -2, /* a HIP runtime call failed; see pcl_last_error()          */
     PCL_ERR_NO_DEVICE    = -3, /* no usable gfx950 device                                  */
-    PCL_ERR_OUT_OF_RANGE = -4  /* first/count outside the particle or cell range           */
+    PCL_ERR_OUT_OF_RANGE = -4, /* first/count outside the particle or cell range           */
+    PCL_ERR_DEVICE       = -5  /* a kernel of the handle flagged a condition only it could see (the order refresh
+                                  reserved more slots than its histogram counted; a cursor record read from device
+                                  memory had an unknown mode or falloff).  Returned once, by the next call that
+                                  synchronises the stream (pcl_synchronize, pcl_read_*, pcl_diagnostics_read,
+                                  pcl_debug_cell_indices, pcl_brush_selection); pcl_last_error() says which */
 };
 
 /* Which kernel family pcl_step picked (see pcl_last_step_kernel). */
@@ -107,9 +112,10 @@ void pcl_sim_params_default(pcl_sim_params* out);
  * Construct.  Replaces Compute::new(device, particles, force_grid),
  * src/compute.rs:25-145: copies both inputs, parameters start as
  * SimParams::new() (delta_t = 0) exactly as compute.rs:33 does.
- * `n` may be 0.  `n_cells` is only checked against the parameter block's
- * dimensions when a step is launched (the reference never checks; an index
- * past the end is clamped to the last cell).
+ * `n` may be 0.  `n_cells` is not compared with the parameter block's
+ * dimensions by the step (the reference never checks either): a cell index
+ * past the end is clamped to the last cell.  Only the brush entry points,
+ * which need the grid's geometry, require dx*dy*dz == n_cells.
  */
 int pcl_create(const pcl_particle* particles, size_t n,
                const float (*force_grid)[4], size_t n_cells,
@@ -193,7 +199,10 @@ void pcl_brush_input_default(pcl_brush_input* out);
  * dimensions from the parameter block) lies within falloff_dist of cursor_pos
  * and remembers their vectors and the cursor position.  Asynchronous.  The
  * _device variant reads the record from device memory (e.g. a buffer that was
- * just broadcast to every GPU). */
+ * just broadcast to every GPU).  The host variants reject a record whose mode
+ * or falloff is not one of the enumerated values with PCL_ERR_INVALID; the
+ * _device variants cannot look at the record before the launch: such a record
+ * then edits nothing and the next synchronising call returns PCL_ERR_DEVICE. */
 int pcl_brush_mouse_down(pcl_compute* h, const pcl_brush_input* in);
 int pcl_brush_mouse_down_device(pcl_compute* h, const void* dev_in);
 
@@ -271,12 +280,17 @@ int pcl_force_pair_kernel(pcl_compute* h, int enable);
  * index order (bit-exact summation order, reproducible).  PCL_PAIRS_BINNED:
  * particles are sorted into cells of edge >= cut_off_distance (or half of it)
  * and only the cells within reach are swept: same skip tests and force
- * expression, O(N k) instead of O(N^2); a particle's terms are added in the
- * order the sort left its partners in, so sums equal the exact sweep's up to
- * fp32 summation order and may differ in the last bits from run to run.
- * At most 20 cells per axis, 64 from 2^18 particles on.
+ * expression, O(N k) instead of O(N^2); a particle's terms are added cell by
+ * cell, within a cell in ascending caller index (the sort is a stable radix
+ * sort of (cell, caller index)), so results are reproducible from run to run
+ * and independent of the memory order before the step, and equal the exact
+ * sweep's up to fp32 summation order.  At most 20 cells per axis, 64 from 2^18
+ * particles on.
  * PCL_PAIRS_AUTO (default): binned from 2^15 particles on when the cut-off
- * allows at least 3 cells per axis, the exact sweep otherwise. */
+ * allows at least 3 cells per axis, the exact sweep otherwise.
+ * pcl_step_pairs_gathered (several handles) always runs the exact sweep, so a
+ * sharded run equals a one-handle run bit for bit only where that one also
+ * runs the exact sweep: under PCL_PAIRS_ALL, or below 2^15 particles. */
 enum { PCL_PAIRS_AUTO = 0, PCL_PAIRS_ALL = 1, PCL_PAIRS_BINNED = 2 };
 int pcl_set_pair_mode(pcl_compute* h, int mode);
 
@@ -402,7 +416,9 @@ int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks,
  *   0xF0     log2 of the cells per sort tile (default 8 = 16 x 16 cells)
  *   0xF000   point of the refresh interval the tile order aims at, in tenths (default 5)
  *   0x10000  cut-off cells of the binned pair term: one-cell reach only
- *   0x20000  cut-off cells: at most 20 per axis */
+ *   0x20000  cut-off cells: at most 20 per axis
+ *   0x40000  tests only: the next refresh of the particle order scatters with other keys than its
+ *            histogram counted, which the kernel reports as PCL_ERR_DEVICE (the state is then unusable) */
 int pcl_set_tuning(pcl_compute* h, uint32_t grid_blocks, uint32_t variant);
 
 #ifdef __cplusplus

@@ -180,7 +180,15 @@ int orc_pair_term_inert(const orc_sim_params* p)
     for (int k = 0; k < 25; ++k)
         for (int c = 0; c < 8; ++c)
             if (p->attraction_force[k].coeffs[c] != 0.0f) return 0;
-    return 1;
+    /* 0 * mass * pow(len, exponent) is +-0 only while both factors are finite */
+    for (int k = 0; k < 5; ++k)
+        if (!isfinite(p->particle_type_masses[k].mass)) return 0;
+    const double e = (double)p->distance_exponent;
+    if (e == 0.0) return 1;
+    if (!isfinite(e)) return 0;
+    const double hi = isfinite(p->cut_off_distance) ? (double)p->cut_off_distance : 3.4028234663852886e38;
+    const double reach = fmax(fabs(log(0.001)), fabs(log(hi)));
+    return fabs(e) * reach <= 69.0;   /* pow(len, e) <= 1e30 for every len in [0.001, cut_off] */
 }
 
 /* ---- one invocation of src/compute.wgsl:97-181 for particle `index` ---- */

@@ -7,7 +7,7 @@ from .particle import PARTICLE_DTYPE, MASS_WRAP_DTYPE, NUM_TYPES, empty_particle
 from .poly7 import POLY7_DTYPE, Poly7
 from .grid import Bounds, Grid
 from .sim_params import SIM_PARAMS_DTYPE, SimParams
-from ._lib import PclError, KERNEL_NONE, KERNEL_STREAM, KERNEL_PAIRS
+from ._lib import PclError, KERNEL_NONE, KERNEL_STREAM, KERNEL_PAIRS, PAIRS_AUTO, PAIRS_ALL, PAIRS_BINNED
 from ._lib import (STEP_NONE, STEP_STREAM, STEP_PAIRS, STEP_STREAM_COUNT, STEP_STREAM_SCATTER, STEP_PAIRS_BINNED,
                    STEP_PAIRS_GATHERED, STEP_STREAM_FUSED)
 from .compute import Compute
@@ -19,5 +19,6 @@ __all__ = [
     "POLY7_DTYPE", "Poly7", "Bounds", "Grid", "SIM_PARAMS_DTYPE", "SimParams",
     "STEP_NONE", "STEP_STREAM", "STEP_PAIRS", "STEP_STREAM_COUNT", "STEP_STREAM_SCATTER", "STEP_PAIRS_BINNED",
     "STEP_PAIRS_GATHERED", "STEP_STREAM_FUSED",
+    "PAIRS_AUTO", "PAIRS_ALL", "PAIRS_BINNED",
     "PclError", "KERNEL_NONE", "KERNEL_STREAM", "KERNEL_PAIRS", "Compute", "ShardedCompute", "shard_range", "Brush", "DeviceBrush", "EditMode", "BRUSH_INPUT_DTYPE",
 ]

@@ -14,6 +14,7 @@ PCL_ERR_INVALID = -1
 PCL_ERR_HIP = -2
 PCL_ERR_NO_DEVICE = -3
 PCL_ERR_OUT_OF_RANGE = -4
+PCL_ERR_DEVICE = -5
 
 KERNEL_NONE, KERNEL_STREAM, KERNEL_PAIRS = 0, 1, 2
 STEP_NONE, STEP_STREAM, STEP_PAIRS, STEP_STREAM_COUNT, STEP_STREAM_SCATTER, STEP_PAIRS_BINNED = 0, 1, 2, 3, 4, 5

@@ -94,15 +94,27 @@ __device__ __forceinline__ V3 brush_get_vector(const BrushInput& in, V3 v, V3 v_
     return scale3(res, in.strength);                                            // :202
 }
 
+// A record whose mode or falloff is none of the enumerated values (possible only
+// for records read from device memory; the host variants reject them before the
+// launch) edits nothing and sets kErrBrushRecord in the error word.
+__device__ __forceinline__ bool brush_record_valid(const BrushInput& in)
+{
+    return in.mode >= 0 && in.mode <= 2 && in.falloff >= 0 && in.falloff <= 2;
+}
+
 // Cursor::mouse_down: src/cursor.rs:105-116.  `state` must be zeroed before the
 // launch.  The selection is appended in arbitrary order (each selected cell is
 // rewritten independently, so the order never reaches the field).
 __global__ __launch_bounds__(kBlockThreads) void brush_select_kernel(
     BrushInput by_value, const BrushInput* __restrict__ from_device, FieldGeometry G, uint32_t n_cells,
     const f32x4* __restrict__ field, BrushState* __restrict__ state, uint32_t* __restrict__ sel_index,
-    f32x4* __restrict__ sel_vector)
+    f32x4* __restrict__ sel_vector, uint32_t* error)
 {
     const BrushInput in = from_device ? *from_device : by_value;
+    if (!brush_record_valid(in)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(error, kErrBrushRecord);
+        return;   // state->count stays 0: an empty selection
+    }
     const V3 cursor = load3(in.cursor_pos);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         state->md_pos[0] = cursor.x; state->md_pos[1] = cursor.y; state->md_pos[2] = cursor.z;
@@ -121,9 +133,13 @@ __global__ __launch_bounds__(kBlockThreads) void brush_select_kernel(
 __global__ __launch_bounds__(kBlockThreads) void brush_apply_kernel(
     BrushInput by_value, const BrushInput* __restrict__ from_device, FieldGeometry G,
     f32x4* __restrict__ field, const BrushState* __restrict__ state, const uint32_t* __restrict__ sel_index,
-    const f32x4* __restrict__ sel_vector)
+    const f32x4* __restrict__ sel_vector, uint32_t* error)
 {
     const BrushInput in = from_device ? *from_device : by_value;
+    if (!brush_record_valid(in)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(error, kErrBrushRecord);
+        return;
+    }
     const V3 md_pos = load3(state->md_pos);
     const uint32_t count = state->count;
     const uint32_t stride = gridDim.x * kBlockThreads;

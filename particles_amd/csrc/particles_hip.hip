@@ -107,17 +107,22 @@ struct pcl_compute {
     int orig_cur = 0;
     uint32_t* slot_of = nullptr;       // inverse of orig, built on demand
     bool slot_of_valid = false;
-    uint32_t* d_hist = nullptr;        // kMaxReorderBins * kCursorGroups counters, then as many cursors
+    uint32_t* d_hist = nullptr;        // kMaxReorderBins * kCursorGroups counters, as many cursors, as many range ends
     size_t reorder_capacity = 0;
     uint64_t steps_since_sort = 0;
     bool hist_valid = false;           // d_hist counts the tile keys of state[cur] (left by a counting step)
     pcl::TileMap hist_tiles;           // the key function that histogram was taken with
     uint64_t reorders = 0;
-    // counting sort with global counters (pair cells beyond kMaxReorderBins)
-    uint32_t* d_wide = nullptr;        // histogram[bins + 1] then start[bins + 1]
-    size_t wide_bins = 0;
-    uint32_t* d_keyrank = nullptr;     // key[capacity] then rank[capacity]
-    size_t keyrank_capacity = 0;
+    // sort by cut-off cell for the binned pair term (stable radix sort of (cell, caller index))
+    uint32_t* d_cellsort = nullptr;    // key in, key out, index in, index out: 4 x capacity
+    size_t cellsort_capacity = 0;
+    void* d_sort_temp = nullptr;       // the radix sort's temporary storage
+    size_t sort_temp_bytes = 0;
+    uint32_t* d_bin_end = nullptr;     // one past the last slot of every cell
+    size_t bin_end_capacity = 0;
+    // conditions only a running kernel can detect (kErr* bits), reported by the next synchronising call
+    uint32_t* d_error = nullptr;
+    uint32_t* h_error = nullptr;       // pinned landing place of the asynchronous copy
     // automatic pacing of the refreshes (reorder_interval == -1)
     int auto_interval = 0;             // current interval; 0 until first used
     uint32_t* d_runs = nullptr;        // bins touched per block, summed by the counting step
@@ -172,6 +177,29 @@ int bind(const pcl_compute* h)
     if (!h) return fail(PCL_ERR_INVALID, "null handle");
     PCL_HIP_TRY(hipSetDevice(h->device));
     return PCL_OK;
+}
+
+// Waits for the handle's stream and reports what its kernels flagged in the
+// device error word since the last report (the word is cleared).
+int sync_stream(pcl_compute* h)
+{
+    if (!h->d_error) {
+        PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+        return PCL_OK;
+    }
+    *h->h_error = 0u;
+    PCL_HIP_TRY(hipMemcpyAsync(h->h_error, h->d_error, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+    const uint32_t bits = *h->h_error;
+    if (bits == 0u) return PCL_OK;
+    PCL_HIP_TRY(hipMemsetAsync(h->d_error, 0, sizeof(uint32_t), h->stream));
+    std::string msg = "a kernel of this handle reported:";
+    if (bits & pcl::kErrScatterOverflow)
+        msg += " the refresh of the particle order reserved more slots for a field tile than its histogram counted"
+               " (particle state may be corrupt: upload the particles again);";
+    if (bits & pcl::kErrBrushRecord)
+        msg += " a cursor record read from device memory had an unknown mode or falloff (that brush event edited nothing);";
+    return fail(PCL_ERR_DEVICE, msg);
 }
 
 void free_particles(pcl_compute* h)
@@ -292,16 +320,28 @@ float smallest_square_with(Pred pred)
     return from_bits(lo);
 }
 
-// The pair loop adds exactly +0 to the acceleration when every polynomial
-// coefficient is +-0, or when no distance can pass both cut-offs
-// (src/compute.wgsl:126-131,139); finite inputs assumed.
+// The pair loop adds exactly +0 to the acceleration when no distance can pass
+// both cut-offs, or when every polynomial coefficient is +-0 AND every factor
+// that multiplies the zero stays finite (src/compute.wgsl:126-131,139:
+// dN * 0 * mass * pow(len, exponent)): the five masses are finite and
+// pow(len, exponent) cannot overflow for any len in [0.001, cut_off] (0 * inf
+// would be NaN).  The overflow test is done on logarithms in double precision
+// with a wide margin (pow <= 1e30), so that every host language evaluates it
+// identically.  Finite particle positions are assumed.
 bool pair_term_inert(const pcl_sim_params& p)
 {
     if (p.cut_off_distance < 0.001f) return true;
     for (int k = 0; k < PCL_NUM_POLYS; ++k)
         for (int c = 0; c < 8; ++c)
             if (p.attraction_force[k].coeffs[c] != 0.0f) return false;
-    return true;
+    for (int k = 0; k < PCL_NUM_TYPES; ++k)
+        if (!std::isfinite(p.particle_type_masses[k].mass)) return false;
+    const double e = (double)p.distance_exponent;
+    if (e == 0.0) return true;
+    if (!std::isfinite(e)) return false;
+    const double hi = std::isfinite(p.cut_off_distance) ? (double)p.cut_off_distance : 3.4028234663852886e38;
+    const double reach = std::max(std::fabs(std::log(0.001)), std::fabs(std::log(hi)));
+    return std::fabs(e) * reach <= 69.0;   // ln(1e30) = 69.08
 }
 
 size_t stream_tiles(size_t n)
@@ -454,7 +494,7 @@ int reserve_reorder(pcl_compute* h)
 {
     if (h->reorder_capacity >= h->capacity && h->d_hist) return PCL_OK;
     PCL_HIP_TRY(hipStreamSynchronize(h->stream));
-    if (!h->d_hist) PCL_HIP_TRY(hipMalloc((void**)&h->d_hist, 2 * kHistEntries * sizeof(uint32_t)));
+    if (!h->d_hist) PCL_HIP_TRY(hipMalloc((void**)&h->d_hist, 3 * kHistEntries * sizeof(uint32_t)));
     if (h->ty_buf[1]) (void)hipFree(h->ty_buf[1]);
     h->ty_buf[1] = nullptr;
     for (int b = 0; b < 2; ++b) {
@@ -493,51 +533,85 @@ void reorder_args(const pcl_compute* h, pcl::ReorderArgs* a)
     a->src_orig = h->sorted ? h->orig[h->orig_cur] : nullptr;
     a->dst_orig = h->orig[h->sorted ? (h->orig_cur ^ 1) : 0];
     a->cursor = nullptr;
+    a->cursor_end = nullptr;
+    a->error = h->d_error;
     a->groups = 1;
     a->n_tiles = 0;
     a->n = h->n;
 }
 
-// Counting sort of state[cur] into state[cur ^ 1] by the keys of `C` with the
-// counters in global memory; leaves start[0 .. n_bins] (start[n_bins] = n) and
-// returns a pointer to it.
-int wide_sort(pcl_compute* h, const pcl::StepUniforms& U, const pcl::TileMap& C, const uint32_t** start_out)
+// Declared in pair_sort.hip (rocPRIM's stable LSD radix sort of (key, value) pairs on bits
+// [0, end_bit) of the key; with temp == nullptr only the temporary storage size is returned).
+}  // namespace
+namespace pcl {
+hipError_t radix_sort_pairs_u32(void* temp, size_t* temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                                const uint32_t* values_in, uint32_t* values_out, size_t n, unsigned end_bit,
+                                hipStream_t stream);
+}
+namespace {
+
+// Reproducible sort of the particles by the cells of `C` from state[cur] into
+// state[cur ^ 1] (see cell_key_kernel); leaves bin_end[b] = one past the last
+// slot of cell b and commits the new order.
+int restore_caller_order(pcl_compute* h);
+void reorder_commit(pcl_compute* h);
+void reorder_args(const pcl_compute* h, pcl::ReorderArgs* a);
+
+int cell_sort(pcl_compute* h, const pcl::StepUniforms& U, const pcl::TileMap& C, const uint32_t** bin_end_out)
 {
-    const size_t entries = (size_t)C.n_bins + 1;
-    if (h->wide_bins < entries) {
+    if (int rc = restore_caller_order(h)) return rc;
+    if (int rc = reserve_reorder(h)) return rc;
+    PCL_REQUIRE(h->n <= 0x7FFFFFFFull, "too many particles for the binned pair term");
+    if (h->cellsort_capacity < h->capacity) {
         PCL_HIP_TRY(hipStreamSynchronize(h->stream));
-        if (h->d_wide) PCL_HIP_TRY(hipFree(h->d_wide));
-        h->d_wide = nullptr;
-        h->wide_bins = 0;
-        PCL_HIP_TRY(hipMalloc((void**)&h->d_wide, 2 * entries * sizeof(uint32_t)));
-        h->wide_bins = entries;
+        if (h->d_cellsort) PCL_HIP_TRY(hipFree(h->d_cellsort));
+        h->d_cellsort = nullptr;
+        h->cellsort_capacity = 0;
+        PCL_HIP_TRY(hipMalloc((void**)&h->d_cellsort, 4 * h->capacity * sizeof(uint32_t)));
+        h->cellsort_capacity = h->capacity;
     }
-    if (h->keyrank_capacity < h->capacity) {
+    if (h->bin_end_capacity < C.n_bins) {
         PCL_HIP_TRY(hipStreamSynchronize(h->stream));
-        if (h->d_keyrank) PCL_HIP_TRY(hipFree(h->d_keyrank));
-        h->d_keyrank = nullptr;
-        h->keyrank_capacity = 0;
-        PCL_HIP_TRY(hipMalloc((void**)&h->d_keyrank, 2 * h->capacity * sizeof(uint32_t)));
-        h->keyrank_capacity = h->capacity;
+        if (h->d_bin_end) PCL_HIP_TRY(hipFree(h->d_bin_end));
+        h->d_bin_end = nullptr;
+        h->bin_end_capacity = 0;
+        PCL_HIP_TRY(hipMalloc((void**)&h->d_bin_end, (size_t)C.n_bins * sizeof(uint32_t)));
+        h->bin_end_capacity = C.n_bins;
     }
-    uint32_t* hist = h->d_wide;
-    uint32_t* start = h->d_wide + h->wide_bins;
-    uint32_t* key = h->d_keyrank;
-    uint32_t* rank = h->d_keyrank + h->keyrank_capacity;
-    PCL_HIP_TRY(hipMemsetAsync(hist, 0, entries * sizeof(uint32_t), h->stream));
-    hipLaunchKernelGGL(pcl::wide_key_rank_kernel, dim3(linear_grid(h, h->n)), dim3(pcl::kBlockThreads), 0, h->stream,
-                       soa_of(h, h->cur), (unsigned long long)h->n, U, C, hist, key, rank);
+    uint32_t* key_in = h->d_cellsort;
+    uint32_t* key_out = key_in + h->cellsort_capacity;
+    uint32_t* idx_in = key_out + h->cellsort_capacity;
+    uint32_t* idx_out = idx_in + h->cellsort_capacity;
+    unsigned end_bit = 1;
+    while (end_bit < 32u && (1ull << end_bit) < (unsigned long long)C.n_bins) ++end_bit;
+    size_t need = 0;
+    PCL_HIP_TRY(pcl::radix_sort_pairs_u32(nullptr, &need, key_in, key_out, idx_in, idx_out, h->n, end_bit, h->stream));
+    if (need > h->sort_temp_bytes) {
+        PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->d_sort_temp) PCL_HIP_TRY(hipFree(h->d_sort_temp));
+        h->d_sort_temp = nullptr;
+        h->sort_temp_bytes = 0;
+        PCL_HIP_TRY(hipMalloc(&h->d_sort_temp, need));
+        h->sort_temp_bytes = need;
+    }
+    hipLaunchKernelGGL(pcl::cell_key_kernel, dim3(linear_grid(h, h->n)), dim3(pcl::kBlockThreads), 0, h->stream,
+                       soa_of(h, h->cur), (unsigned long long)h->n, U, C, key_in, idx_in);
     PCL_HIP_TRY(hipGetLastError());
-    // the extra zero entry makes the scan leave the total, n, in start[n_bins]
-    hipLaunchKernelGGL(pcl::reorder_scan_kernel, dim3(1), dim3(1024), 0, h->stream, (const uint32_t*)hist,
-                       (uint32_t)entries, 1u, start);
+    size_t temp_bytes = h->sort_temp_bytes;
+    PCL_HIP_TRY(pcl::radix_sort_pairs_u32(h->d_sort_temp, &temp_bytes, key_in, key_out, idx_in, idx_out, h->n, end_bit,
+                                          h->stream));
+    const uint32_t end_blocks = (C.n_bins + pcl::kBlockThreads - 1) / pcl::kBlockThreads;
+    hipLaunchKernelGGL(pcl::cell_end_kernel, dim3(end_blocks), dim3(pcl::kBlockThreads), 0, h->stream,
+                       (const uint32_t*)key_out, (unsigned long long)h->n, C.n_bins, h->d_bin_end);
     PCL_HIP_TRY(hipGetLastError());
     pcl::ReorderArgs ra;
     reorder_args(h, &ra);
-    hipLaunchKernelGGL(pcl::wide_scatter_kernel, dim3(linear_grid(h, h->n)), dim3(pcl::kBlockThreads), 0, h->stream,
-                       ra, (const uint32_t*)start, (const uint32_t*)key, (const uint32_t*)rank);
+    hipLaunchKernelGGL(pcl::cell_gather_kernel, dim3(linear_grid(h, h->n)), dim3(pcl::kBlockThreads), 0, h->stream,
+                       ra, (const uint32_t*)idx_out);
     PCL_HIP_TRY(hipGetLastError());
-    *start_out = start;
+    reorder_commit(h);
+    h->steps_since_sort = 0;
+    *bin_end_out = h->d_bin_end;
     return PCL_OK;
 }
 
@@ -547,10 +621,13 @@ int reorder_prepare(pcl_compute* h, const pcl::TileMap& T, uint32_t groups, pcl:
 {
     uint32_t* hist = h->d_hist;
     uint32_t* cursor = h->d_hist + kHistEntries;
-    hipLaunchKernelGGL(pcl::reorder_scan_kernel, dim3(1), dim3(1024), 0, h->stream, (const uint32_t*)hist, T.n_bins, groups, cursor);
+    uint32_t* cursor_end = h->d_hist + 2 * kHistEntries;
+    hipLaunchKernelGGL(pcl::reorder_scan_kernel, dim3(1), dim3(1024), 0, h->stream, (const uint32_t*)hist, T.n_bins, groups,
+                       cursor, cursor_end);
     PCL_HIP_TRY(hipGetLastError());
     reorder_args(h, a);
     a->cursor = cursor;
+    a->cursor_end = cursor_end;
     a->groups = groups;
     const size_t full_tiles = (h->n / 4 + pcl::kStreamThreads - 1) / pcl::kStreamThreads;
     a->n_tiles = (uint32_t)std::min<size_t>(full_tiles, 0x7FFFFFFFu);
@@ -720,7 +797,10 @@ int do_step_impl(pcl_compute* h, int* kind)
         const int interval = effective_reorder_interval(h);
         const bool sort_now = interval > 0 && (!h->sorted || h->steps_since_sort >= (uint64_t)interval);
         // A pending histogram fixes the key function (delta_t, hence the lookahead, may change per frame).
-        const pcl::TileMap T = (sort_now && h->hist_valid) ? h->hist_tiles : make_tile_map(h->params, interval, tile_log2(h), tile_aim(h));
+        pcl::TileMap T = (sort_now && h->hist_valid) ? h->hist_tiles : make_tile_map(h->params, interval, tile_log2(h), tile_aim(h));
+        // tuning bit 0x40000 (tests only): scatter with other keys than the pending histogram counted,
+        // which the scatter kernel must detect and report through the error word
+        if (sort_now && h->hist_valid && (h->variant & 0x40000u)) T.lookahead += 1.0f;
         if (sort_now) {
             // Update and scatter into tile order in one pass.
             if (int rc = reserve_reorder(h)) return rc;
@@ -831,27 +911,11 @@ int do_step_impl(pcl_compute* h, int* kind)
             PCL_HIP_TRY(hipStreamSynchronize(h->stream));
             h->params_dirty = false;
         }
-        if (int rc = reserve_reorder(h)) return rc;
         // tuning bits: 0x10000 one-cell reach only, 0x20000 at most 20 cells per axis
         const pcl::TileMap C = make_pair_cell_map(h->params, (h->variant & 0x10000u) == 0,
                                                   ((h->variant & 0x20000u) || h->n < kPairWideMinParticles) ? 20u : kPairMaxCellsPerAxis);
         const uint32_t* bin_end = nullptr;   // bin_end[b]: one past the last slot of cell b
-        if (C.n_bins > pcl::kMaxReorderBins) {
-            const uint32_t* start = nullptr;
-            if (int rc = wide_sort(h, U, C, &start)) return rc;
-            bin_end = start + 1;
-        } else {
-            if (int rc = reorder_count(h, U, C, 1)) return rc;   // one cursor per cell: the sweep needs each cell's end
-            pcl::ReorderArgs ra;
-            uint32_t sgrid = 0;
-            if (int rc = reorder_prepare(h, C, 1, &ra, &sgrid)) return rc;
-            hipLaunchKernelGGL(pcl::reorder_scatter_kernel, dim3(sgrid), dim3(pcl::kStreamThreads),
-                               pcl::scatter_lds_bytes(C.n_bins), h->stream, ra, U, C);
-            PCL_HIP_TRY(hipGetLastError());
-            bin_end = h->d_hist + kHistEntries;   // the cursors after the scatter
-        }
-        reorder_commit(h);
-        h->steps_since_sort = 0;
+        if (int rc = cell_sort(h, U, C, &bin_end)) return rc;
         const size_t blocks = (h->n + pcl::kBlockThreads - 1) / pcl::kBlockThreads;
         PCL_REQUIRE(blocks <= 0x7FFFFFFFu, "too many particles for the pair kernel");
         grid = (uint32_t)blocks;
@@ -1049,7 +1113,7 @@ int brush_mouse_down(pcl_compute* h, const pcl_brush_input* host_in, const void*
     hipLaunchKernelGGL(pcl::brush_select_kernel, dim3(linear_grid(h, h->n_cells)), dim3(pcl::kBlockThreads), 0,
                        h->stream, brush_input_of(host_in), static_cast<const pcl::BrushInput*>(dev_in), G,
                        (uint32_t)h->n_cells, (const pcl::f32x4*)h->field, h->d_brush_state, h->d_brush_index,
-                       h->d_brush_vector);
+                       h->d_brush_vector, h->d_error);
     PCL_HIP_TRY(hipGetLastError());
     h->brush_down = true;
     return PCL_OK;
@@ -1067,7 +1131,7 @@ int brush_mouse_moved(pcl_compute* h, const pcl_brush_input* host_in, const void
     hipLaunchKernelGGL(pcl::brush_apply_kernel, dim3(grid), dim3(pcl::kBlockThreads), 0, h->stream,
                        brush_input_of(host_in), static_cast<const pcl::BrushInput*>(dev_in), G, h->field,
                        (const pcl::BrushState*)h->d_brush_state, (const uint32_t*)h->d_brush_index,
-                       (const pcl::f32x4*)h->d_brush_vector);
+                       (const pcl::f32x4*)h->d_brush_vector, h->d_error);
     PCL_HIP_TRY(hipGetLastError());
     return PCL_OK;
 }
@@ -1111,8 +1175,11 @@ int pcl_destroy(pcl_compute* h)
     if (h->d_diag) (void)hipFree(h->d_diag);
     if (h->d_hist) (void)hipFree(h->d_hist);
     if (h->d_runs) (void)hipFree(h->d_runs);
-    if (h->d_wide) (void)hipFree(h->d_wide);
-    if (h->d_keyrank) (void)hipFree(h->d_keyrank);
+    if (h->d_cellsort) (void)hipFree(h->d_cellsort);
+    if (h->d_sort_temp) (void)hipFree(h->d_sort_temp);
+    if (h->d_bin_end) (void)hipFree(h->d_bin_end);
+    if (h->d_error) (void)hipFree(h->d_error);
+    if (h->h_error) (void)hipHostFree(h->h_error);
     if (h->h_runs) (void)hipHostFree(h->h_runs);
     if (h->ev_runs) (void)hipEventDestroy(h->ev_runs);
     if (h->d_brush_state) (void)hipFree(h->d_brush_state);
@@ -1164,6 +1231,9 @@ int pcl_create(const pcl_particle* particles, size_t n, const float (*force_grid
     PCL_CREATE_TRY(hipEventCreate(&h->ev_stop));
     PCL_CREATE_TRY(hipMalloc((void**)&h->d_params, sizeof(pcl_sim_params)));
     PCL_CREATE_TRY(hipMalloc((void**)&h->d_diag, sizeof(pcl::DiagOut)));
+    PCL_CREATE_TRY(hipMalloc((void**)&h->d_error, sizeof(uint32_t)));
+    PCL_CREATE_TRY(hipMemset(h->d_error, 0, sizeof(uint32_t)));
+    PCL_CREATE_TRY(hipHostMalloc((void**)&h->h_error, sizeof(uint32_t), hipHostMallocDefault));
 #undef PCL_CREATE_TRY
     if (int rc = reserve_partials(h, 1)) return cleanup(rc);
     if (int rc = pcl_update_force_grid(h, force_grid, n_cells)) return cleanup(rc);
@@ -1392,7 +1462,7 @@ int pcl_brush_selection(pcl_compute* h, uint32_t* out_indices, size_t capacity, 
     *count = 0;
     if (!h->brush_down) return PCL_OK;
     if (int rc = bind(h)) return rc;
-    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = sync_stream(h)) return rc;
     pcl::BrushState st;
     PCL_HIP_TRY(hipMemcpy(&st, h->d_brush_state, sizeof st, hipMemcpyDeviceToHost));
     *count = st.count;
@@ -1417,8 +1487,7 @@ int pcl_read_force_grid(pcl_compute* h, float (*out)[4], size_t first_cell, size
     PCL_REQUIRE(out, "null output");
     if (int rc = bind(h)) return rc;
     PCL_HIP_TRY(hipMemcpyAsync(out, h->field + first_cell, count * sizeof(pcl::f32x4), hipMemcpyDeviceToHost, h->stream));
-    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
-    return PCL_OK;
+    return sync_stream(h);
 }
 
 int pcl_update_sim_params(pcl_compute* h, const pcl_sim_params* params)
@@ -1543,6 +1612,7 @@ int pcl_read_particles(pcl_compute* h, pcl_particle* out, size_t first, size_t c
         if (e != hipSuccess) rc = fail(PCL_ERR_HIP, std::string("pcl_read_particles: ") + hipGetErrorString(e));
     }
     (void)hipFree(staging);
+    if (rc == PCL_OK) rc = sync_stream(h);
     return rc;
 }
 
@@ -1561,8 +1631,7 @@ int pcl_read_soa(pcl_compute* h, size_t first, size_t count, float* x, float* y,
                 PCL_HIP_TRY(hipMemcpyAsync(dst[a], h->state[h->cur][a] + first, count * sizeof(float),
                                            hipMemcpyDeviceToHost, h->stream));
         if (ty) PCL_HIP_TRY(hipMemcpyAsync(ty, cur_ty(h) + first, count, hipMemcpyDeviceToHost, h->stream));
-        PCL_HIP_TRY(hipStreamSynchronize(h->stream));
-        return PCL_OK;
+        return sync_stream(h);
     }
     // Tile order: gather the range into caller order on the device first.
     char* tmp = nullptr;
@@ -1580,7 +1649,7 @@ int pcl_read_soa(pcl_compute* h, size_t first, size_t count, float* x, float* y,
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     (void)hipFree(tmp);
     if (e != hipSuccess) return fail(PCL_ERR_HIP, std::string("pcl_read_soa: ") + hipGetErrorString(e));
-    return PCL_OK;
+    return sync_stream(h);
 }
 
 int pcl_pack_particles_device(pcl_compute* h, void* dev_out, size_t first, size_t count)
@@ -1625,8 +1694,7 @@ int pcl_diagnostics_read(pcl_compute* h, pcl_diagnostics* out)
     PCL_REQUIRE(out != nullptr, "pcl_diagnostics_read: out is null");
     if (int rc = ensure_diag(h)) return rc;
     PCL_HIP_TRY(hipMemcpyAsync(out, h->d_diag, sizeof(pcl_diagnostics), hipMemcpyDeviceToHost, h->stream));
-    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
-    return PCL_OK;
+    return sync_stream(h);
 }
 
 int pcl_diagnostics_device(pcl_compute* h, void* dev_out)
@@ -1657,7 +1725,7 @@ int pcl_debug_cell_indices(pcl_compute* h, uint32_t* out, size_t first, size_t c
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(PCL_ERR_HIP, std::string("pcl_debug_cell_indices: ") + hipGetErrorString(e));
-    return PCL_OK;
+    return sync_stream(h);
 }
 
 int pcl_set_stream(pcl_compute* h, void* hip_stream)
@@ -1680,8 +1748,7 @@ int pcl_use_null_stream(pcl_compute* h)
 int pcl_synchronize(pcl_compute* h)
 {
     if (int rc = bind(h)) return rc;
-    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
-    return PCL_OK;
+    return sync_stream(h);
 }
 
 int pcl_timer_start(pcl_compute* h)

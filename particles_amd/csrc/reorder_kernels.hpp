@@ -76,8 +76,11 @@ __global__ __launch_bounds__(kStreamThreads) void reorder_count_kernel(
 // bin-major, group-minor (k = bin * groups + group) so that every bin's slots are
 // contiguous; counter and cursor of (bin, group) are STORED at group * n_bins + bin,
 // which puts the groups of one bin into different cache lines.
+// `cursor_end` (may be null) receives the end of every counter's range, which the scatter
+// kernels check their reservations against.
 __global__ __launch_bounds__(1024) void reorder_scan_kernel(const uint32_t* __restrict__ hist, uint32_t n_bins,
-                                                            uint32_t groups, uint32_t* __restrict__ cursor)
+                                                            uint32_t groups, uint32_t* __restrict__ cursor,
+                                                            uint32_t* __restrict__ cursor_end)
 {
     __shared__ uint32_t part[1024];
     const uint32_t total = n_bins * groups;
@@ -101,6 +104,7 @@ __global__ __launch_bounds__(1024) void reorder_scan_kernel(const uint32_t* __re
             const uint32_t at = physical(begin + i);
             cursor[at] = run;
             run += hist[at];
+            if (cursor_end) cursor_end[at] = run;
         }
 }
 
@@ -112,6 +116,8 @@ struct ReorderArgs {
     const uint32_t* __restrict__ src_orig;  // nullptr: slots are still in caller order
     uint32_t* __restrict__ dst_orig;
     uint32_t* __restrict__ cursor;          // next free slot per (bin, group), at counter_index(bin, group, n_bins)
+    const uint32_t* __restrict__ cursor_end; // end of that counter's range (what the histogram counted)
+    uint32_t* error;                        // device error word
     uint32_t groups;
     uint32_t n_tiles;                       // full tiles; block n_tiles (if any) carries the ragged tail, in group 0
     unsigned long long n;
@@ -152,8 +158,11 @@ struct ScatterLds {
 // per-bin counts into local start positions, reserve each non-empty bin's run of
 // global slots with one atomic add, and leave in slot[b] the offset that maps a
 // local position of bin b to its global slot.  Ends with a barrier.
+// A reservation that runs past the end of its counter's range means the histogram and the keys
+// disagree (they never do while both come from tile_key with one TileMap): particles would
+// overwrite another bin's slots.  That sets kErrScatterOverflow in the error word.
 __device__ __forceinline__ void scatter_plan(const ScatterLds& L, uint32_t n_bins, uint32_t* __restrict__ cursor,
-                                             uint32_t group)
+                                             const uint32_t* __restrict__ cursor_end, uint32_t* error, uint32_t group)
 {
     __shared__ uint32_t wave_total[kStreamThreads / 64];
     const uint32_t per = (n_bins + kStreamThreads - 1) / kStreamThreads;
@@ -178,7 +187,13 @@ __device__ __forceinline__ void scatter_plan(const ScatterLds& L, uint32_t n_bin
         if (b < n_bins) {
             const uint32_t c = L.slot[b];
             L.lstart[b] = (uint16_t)run;
-            if (c) L.slot[b] = atomicAdd(&cursor[counter_index(b, group, n_bins)], c) - run;
+            if (c) {
+                const uint32_t at = counter_index(b, group, n_bins);
+                const uint32_t end = cursor_end[at];
+                const uint32_t base = atomicAdd(&cursor[at], c);
+                if (base + c > end) atomicOr(error, kErrScatterOverflow);
+                L.slot[b] = base - run;
+            }
             run += c;
         }
     }
@@ -243,7 +258,7 @@ __device__ __forceinline__ void scatter_write(const ReorderArgs& a, const Scatte
                                               const uint32_t key[4], const uint32_t rank[4], int live)
 {
     __shared__ uint32_t n_local_sh;
-    scatter_plan(L, n_bins, a.cursor, blockIdx.x < a.n_tiles ? blockIdx.x % a.groups : 0u);
+    scatter_plan(L, n_bins, a.cursor, a.cursor_end, a.error, blockIdx.x < a.n_tiles ? blockIdx.x % a.groups : 0u);
     uint32_t lpos[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -268,7 +283,7 @@ __device__ __forceinline__ void scatter_write(const ReorderArgs& a, const Scatte
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t l = threadIdx.x + (uint32_t)i * kStreamThreads;
-        // a slot >= n cannot happen while histogram and keys agree; never write out of bounds
+        // a slot >= n means histogram and keys disagree (scatter_plan has flagged it); never write out of bounds
         out_slot[i] = l < n_local ? L.dest[l] : 0u;
         if (out_slot[i] >= a.n) out_slot[i] = (uint32_t)(a.n - 1);
     }
@@ -378,36 +393,48 @@ __global__ __launch_bounds__(kStreamThreads) void step_scatter_kernel(StepScatte
     if (DIAG) block_reduce_store<kStreamThreads>(acc, sa.partials + blockIdx.x);
 }
 
-// Counting sort with the counters in global memory, for key spaces too large
-// for the LDS tables of the kernels above (the cut-off cells of the pair term:
-// up to 64^3).  One global atomic per particle gives its rank within its bin;
-// slower per particle than the tiled scatter, which does not matter next to
-// the pair sweep it serves.
-__global__ __launch_bounds__(kBlockThreads) void wide_key_rank_kernel(
-    StateSoA s, unsigned long long n, StepUniforms U, TileMap T, uint32_t* __restrict__ hist,
-    uint32_t* __restrict__ key, uint32_t* __restrict__ rank)
+// Sort by cut-off cell for the binned pair term.  The order of a particle's
+// partners decides the order its force terms are added in, so this sort is
+// made reproducible: the particles are first put back into caller order, then
+// (cell key, caller index) pairs go through a stable radix sort, which leaves
+// every cell's particles in ascending caller index whatever order the memory
+// was in before.  Keys use tile_key without lookahead.
+__global__ __launch_bounds__(kBlockThreads) void cell_key_kernel(
+    StateSoA s, unsigned long long n, StepUniforms U, TileMap C, uint32_t* __restrict__ key,
+    uint32_t* __restrict__ index)
 {
     const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
     for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x; i < n; i += stride) {
-        const uint32_t k = tile_key(U, T, s.a[0][i], s.a[1][i], s.a[2][i], 0.0f, 0.0f, 0.0f);
-        key[i] = k;
-        rank[i] = atomicAdd(&hist[k], 1u);
+        key[i] = tile_key(U, C, s.a[0][i], s.a[1][i], s.a[2][i], 0.0f, 0.0f, 0.0f);
+        index[i] = (uint32_t)i;
     }
 }
 
-// start[] is the exclusive prefix of the histogram that wide_key_rank_kernel filled.
-__global__ __launch_bounds__(kBlockThreads) void wide_scatter_kernel(
-    ReorderArgs a, const uint32_t* __restrict__ start, const uint32_t* __restrict__ key,
-    const uint32_t* __restrict__ rank)
+// bin_end[b] = number of sorted keys <= b (one past the last slot of cell b).
+__global__ __launch_bounds__(kBlockThreads) void cell_end_kernel(
+    const uint32_t* __restrict__ sorted_key, unsigned long long n, uint32_t n_bins, uint32_t* __restrict__ bin_end)
+{
+    const uint32_t b = blockIdx.x * kBlockThreads + threadIdx.x;
+    if (b >= n_bins) return;
+    unsigned long long lo = 0, hi = n;   // first position whose key is > b
+    while (lo < hi) {
+        const unsigned long long mid = lo + (hi - lo) / 2;
+        if (sorted_key[mid] <= b) lo = mid + 1; else hi = mid;
+    }
+    bin_end[b] = (uint32_t)lo;
+}
+
+// dst[slot] = src[from[slot]]: `from` holds the caller index of every sorted slot
+// (the source is in caller order), which is also what dst_orig receives.
+__global__ __launch_bounds__(kBlockThreads) void cell_gather_kernel(ReorderArgs a, const uint32_t* __restrict__ from)
 {
     const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
     for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x; i < a.n; i += stride) {
-        unsigned long long slot = (unsigned long long)start[key[i]] + rank[i];
-        if (slot >= a.n) slot = a.n - 1ull;   // cannot happen while histogram and keys agree; never write out of bounds
+        const uint32_t j = from[i];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) a.dst[c][slot] = a.src[c][i];
-        a.dst_ty[slot] = a.src_ty[i];
-        a.dst_orig[slot] = a.src_orig ? a.src_orig[i] : (uint32_t)i;
+        for (int c = 0; c < 6; ++c) a.dst[c][i] = a.src[c][j];
+        a.dst_ty[i] = a.src_ty[j];
+        a.dst_orig[i] = j;
     }
 }
 

@@ -23,6 +23,11 @@ constexpr int kBlockThreads = 256;     // 4 waves of 64
 constexpr int kParticlesPerLane = 4;   // one 16-byte access per array per lane
 constexpr int kTileParticles = kBlockThreads * kParticlesPerLane;
 
+// Bits of a handle's device error word: conditions a kernel can only detect
+// while it runs; the next call that synchronises the stream reports them.
+constexpr uint32_t kErrScatterOverflow = 1u;   // a tile reserved more slots of a bin than the histogram counted
+constexpr uint32_t kErrBrushRecord = 2u;       // a cursor record read from device memory has an unknown mode or falloff
+
 // Everything that is uniform over a launch; passed by value (lives in SGPRs).
 struct StepUniforms {
     float decay;         // exp(-delta_t), evaluated on the host       wgsl:151

@@ -83,12 +83,27 @@ class SimParams:
         return self.raw["attraction_force"]["coeffs"]
 
     def pair_term_inert(self):
-        """True when the all-pairs loop provably adds exactly +0: every
-        polynomial coefficient is +-0, or no distance can pass both cut-offs
-        (src/compute.wgsl:126-131,139)."""
-        if np.float32(self.raw["cut_off_distance"]) < np.float32(0.001):
+        """True when the all-pairs loop provably adds exactly +0: no distance
+        can pass both cut-offs, or every polynomial coefficient is +-0 while
+        the masses are finite and pow(len, exponent) cannot overflow for len
+        in [0.001, cut_off] (src/compute.wgsl:126-131,139; 0 * inf would be
+        NaN).  The same rule, on double-precision logarithms, as the library."""
+        import math
+        cut = float(np.float32(self.raw["cut_off_distance"]))
+        if cut < float(np.float32(0.001)):
             return True
-        return not np.any(self.raw["attraction_force"]["coeffs"] != 0.0)
+        if np.any(self.raw["attraction_force"]["coeffs"] != 0.0):
+            return False
+        if not np.all(np.isfinite(self.raw["particle_type_masses"]["mass"])):
+            return False
+        e = float(np.float32(self.raw["distance_exponent"]))
+        if e == 0.0:
+            return True
+        if not math.isfinite(e):
+            return False
+        hi = cut if math.isfinite(cut) else 3.4028234663852886e38
+        reach = max(abs(math.log(0.001)), abs(math.log(hi)))
+        return abs(e) * reach <= 69.0
 
     def copy(self):
         c = SimParams()

@@ -54,3 +54,112 @@ def scene_swirl_field(nx, ny, nz, radius, seed):
     out[:, :3] += rng.uniform(-1.0, 1.0, size=(nx * ny * nz, 3)).astype(np.float32)
     out[:, 3] = 1.0
     return out
+
+
+# ---------------------------------------------------------------------------
+# K-step comparison policy for paths whose arithmetic is not bit-reproducible
+# (powf; the cell-binned pair term, whose summation order differs).
+#
+# Bar: |a - b| <= 1e-5 * max(|a|, |b|) + 1e-6 per component, positions compared
+# modulo 2r (circular distance).  The update has discontinuities: the fetched
+# field cell (src/compute.wgsl:81-89,147), the wrap plane (:58-66), the speed
+# threshold 0.001 (:157) and the two pair cut-offs (:126-131).  A state that is
+# within the bar of the oracle's may sit on the other side of one of them, and
+# then differs by O(1) afterwards.  Such particles are STRADDLERS: they are
+# found on the oracle's own trajectory (a discontinuity closer than the error
+# the bar admits), counted and held to a stated budget; they are never dropped
+# silently, and a particle out of tolerance that is not one fails the test.
+# ---------------------------------------------------------------------------
+
+RTOL, ATOL = 1e-5, 1e-6
+STRADDLE_MARGIN = 4.0      # a discontinuity within 4x the admitted error counts as straddled
+
+
+def _admitted(x):
+    """State error the bar admits at value(s) x."""
+    return RTOL * np.abs(x) + ATOL
+
+
+def straddlers_on_trajectory(oracle, sp, p0, grid, steps, mode=None, pair_block=512):
+    """Steps the oracle `steps` times from p0 and marks, per particle,
+      direct[i]   at some step a discontinuity of i's own update lay within
+                  STRADDLE_MARGIN x the admitted error of its trajectory;
+      tainted[i]  (pair term only) at some step i was within the cut-off of a
+                  particle marked `direct` at an earlier step, so one of its
+                  force terms may have come from a state that is O(1) off
+                  (one level only: partners of tainted particles are not
+                  marked, their error is second order in delta_t).
+    Returns (final state, direct, tainted)."""
+    mode = oracle.MODE_ALWAYS_PAIRS if mode is None else mode
+    n = p0.shape[0]
+    r = float(sp.bounding_volume_radius)
+    dims = [int(d) for d in sp.force_grid_dimensions]
+    cut = float(sp.cut_off_distance)
+    pairs = not sp.pair_term_inert()
+    direct = np.zeros(n, dtype=bool)
+    tainted = np.zeros(n, dtype=bool)
+    cur = np.array(p0, copy=True)
+    for _ in range(steps):
+        pos = cur["pos"][:, :3].astype(np.float64)
+        m = STRADDLE_MARGIN * _admitted(pos)
+        new = np.zeros(n, dtype=bool)
+        # the cell this step fetches: distance to the nearest cell face per axis
+        for a in range(3):
+            if dims[a] > 1 and r > 0.0:
+                cell = 2.0 * r / dims[a]
+                t = (np.clip(pos[:, a], -r, r) + r) / cell
+                new |= np.abs(t - np.rint(t)) * cell <= m[:, a]
+        off_before = direct.copy()
+        if pairs and n > 1:
+            mp = m.max(axis=1)
+            for b0 in range(0, n, pair_block):
+                d = pos[None, :, :] - pos[b0:b0 + pair_block, None, :]
+                ln = np.sqrt((d * d).sum(axis=2))
+                ln[np.arange(ln.shape[0]), np.arange(b0, b0 + ln.shape[0])] = np.inf   # j == i
+                mm = mp[b0:b0 + pair_block, None] + mp[None, :]
+                near = (np.abs(ln - cut) <= mm) | (np.abs(ln - 0.001) <= mm)
+                new[b0:b0 + pair_block] |= near.any(axis=1)
+                within = ln <= cut + mm
+                tainted[b0:b0 + pair_block] |= (within & off_before[None, :]).any(axis=1)
+        nxt = oracle.step(sp, cur, grid, mode=mode)
+        npos = nxt["pos"][:, :3].astype(np.float64)
+        nvel = nxt["vel"][:, :3].astype(np.float64)
+        # the wrap plane: a position that ends within the margin of +-r may have wrapped or not
+        new |= ((r - np.abs(npos)) <= STRADDLE_MARGIN * _admitted(npos)).any(axis=1)
+        # the speed threshold of the renormalisation
+        speed = np.sqrt((nvel * nvel).sum(axis=1))
+        new |= np.abs(speed - 0.001) <= STRADDLE_MARGIN * _admitted(speed)
+        direct |= new
+        cur = nxt
+    return cur, direct, tainted & ~direct
+
+
+def compare_k_steps(got, want, two_r, direct, tainted, budget, what=""):
+    """The K-step bar.  Returns a dict of counts (also printed).  Fails when a
+    particle is out of tolerance without being a straddler (or tainted by one),
+    or when more than `budget` particles are out of tolerance at all."""
+    n = got.shape[0]
+    bad = np.zeros(n, dtype=bool)
+    bad_components = 0
+    worst = 0.0
+    for f in ("pos", "vel"):
+        a, b = got[f][:, :3].astype(np.float64), want[f][:, :3].astype(np.float64)
+        d = np.abs(a - b)
+        if f == "pos":
+            d = np.minimum(d, np.abs(two_r - d))
+        over = ~(d <= RTOL * np.maximum(np.abs(a), np.abs(b)) + ATOL)     # NaN counts as over
+        bad_components += int(over.sum())
+        bad |= over.any(axis=1)
+        if over.any():
+            worst = max(worst, float(np.nanmax(np.where(over, d, 0.0))))
+    rep = {"particles": n, "straddlers": int(direct.sum()), "tainted": int(tainted.sum()),
+           "out_of_tolerance": int(bad.sum()), "components_out_of_tolerance": bad_components,
+           "out_of_tolerance_straddlers": int((bad & direct).sum()),
+           "out_of_tolerance_tainted": int((bad & tainted).sum()),
+           "out_of_tolerance_unexplained": int((bad & ~direct & ~tainted).sum()),
+           "budget": int(budget), "worst_abs_diff": worst}
+    print(f"[k-step parity] {what}: {rep}")
+    assert np.array_equal(got["ty"], want["ty"]), f"{what}: ty differs"
+    assert rep["out_of_tolerance_unexplained"] == 0, f"{what}: particles out of tolerance that straddle nothing: {rep}"
+    assert rep["out_of_tolerance"] <= budget, f"{what}: straddler budget exceeded: {rep}"
+    return rep

@@ -393,9 +393,7 @@ def test_step_timing_reports_each_launch_and_its_kind():
 # ---- cell-binned pair term: same terms, different summation order
 
 def _close(got, want, two_r, rtol=1e-5, atol=1e-6):
-    """|a-b| <= rtol*max(|a|,|b|) + atol, positions modulo the wrap.  A different
-    summation order perturbs each acceleration by ~eps times the size of its
-    TERMS (which cancel), so callers pass an atol scaled to the accelerations."""
+    """|a-b| <= rtol*max(|a|,|b|) + atol, positions modulo the wrap."""
     for f in ("pos", "vel"):
         a, b = got[f][:, :3].astype(np.float64), want[f][:, :3].astype(np.float64)
         d = np.abs(a - b)
@@ -403,6 +401,34 @@ def _close(got, want, two_r, rtol=1e-5, atol=1e-6):
             d = np.minimum(d, np.abs(two_r - d))       # modulo the wrap
         bad = d > rtol * np.maximum(np.abs(a), np.abs(b)) + atol
         assert not bad.any(), f"{f}: {bad.sum()} components out of tolerance, worst {d.max()}"
+
+
+def _binned_single_step_check(oracle, sp, p_all, g, got, want, first, what):
+    """One step of the binned kernel against the oracle under the plain bar
+    (1e-5*max(|a|,|b|) + 1e-6, straddlers of the step accounted for).  A
+    different summation order perturbs a sum by about eps times the size of
+    its TERMS, which cancel; components that miss the plain bar for that reason
+    alone are counted, printed and held to 1 % of all components, and each
+    must still be within eps-scale of the scene's largest velocity change."""
+    from conftest import RTOL, ATOL
+    two_r = 2.0 * float(sp.bounding_volume_radius)
+    n = got.shape[0]
+    p0 = p_all[first:first + n]
+    dv = float(np.abs(want["vel"][:, :3] - p0["vel"][:, :3] * np.float32(np.exp(-float(sp.delta_t)))).max())
+    plain_bad = 0
+    for f in ("pos", "vel"):
+        a, b = got[f][:, :3].astype(np.float64), want[f][:, :3].astype(np.float64)
+        d = np.abs(a - b)
+        if f == "pos":
+            d = np.minimum(d, np.abs(two_r - d))
+        over = d > RTOL * np.maximum(np.abs(a), np.abs(b)) + ATOL
+        plain_bad += int(over.sum())
+        wide = d > RTOL * np.maximum(np.abs(a), np.abs(b)) + ATOL + 1e-5 * dv
+        assert not wide.any(), f"{what}: {f}: {wide.sum()} components beyond the summation-order bound, worst {d.max()}"
+    print(f"[binned, one step] {what}: {plain_bad} of {6 * n} components miss the plain bar "
+          f"(largest velocity change in the scene {dv:.3g})")
+    assert plain_bad <= max(1, (6 * n) // 100), f"{what}: {plain_bad} components miss 1e-5*max(|a|,|b|)+1e-6"
+    assert np.array_equal(got["ty"], want["ty"])
 
 
 @pytest.mark.parametrize("n,cutoff,extent,exponent", [
@@ -420,11 +446,7 @@ def test_binned_pair_kernel_matches_oracle(oracle, n, cutoff, extent, exponent):
         got = c.read_particles()
         assert c.last_step_kernel == pa.KERNEL_PAIRS
     want = oracle.run(sp, p, g, 1)
-    # scale of the velocity changes in this scene (accelerations * dt)
-    dv = np.abs(want["vel"][:, :3] - p["vel"][:, :3] * np.float32(np.exp(-float(sp.delta_t)))).max()
-    _close(got, want, 2.0 * sp.bounding_volume_radius, atol=1e-6 + 1e-5 * float(dv))
-    # the fetch index does not depend on the summation order: exact
-    assert np.array_equal(got["ty"], want["ty"])
+    _binned_single_step_check(oracle, sp, p, g, got, want, 0, f"n={n} cut-off {cutoff} extent {extent} exponent {exponent}")
 
 
 def test_binned_pairs_many_cells_sorted_with_global_counters(oracle):
@@ -442,9 +464,8 @@ def test_binned_pairs_many_cells_sorted_with_global_counters(oracle):
         c.compute()                              # automatic mode: binned, 64^3 cells, two-cell reach
         assert c.last_step_kernel == pa.KERNEL_PAIRS
         got = np.concatenate([c.read_particles(0, 300), c.read_particles(n - 300, 300)])
-    want = np.concatenate([oracle.step_range(sp, p, g, 0, 300), oracle.step_range(sp, p, g, n - 300, 300)])
-    dv = np.abs(want["vel"][:, :3] - np.concatenate([p[:300], p[-300:]])["vel"][:, :3] * np.float32(np.exp(-float(sp.delta_t)))).max()
-    _close(got, want, 2.0 * sp.bounding_volume_radius, atol=1e-6 + 1e-5 * float(dv))
+    _binned_single_step_check(oracle, sp, p, g, got[:300], oracle.step_range(sp, p, g, 0, 300), 0, "2^18, first 300")
+    _binned_single_step_check(oracle, sp, p, g, got[300:], oracle.step_range(sp, p, g, n - 300, 300), n - 300, "2^18, last 300")
 
 
 def test_binned_and_exact_pair_kernels_agree_over_steps(oracle):
@@ -579,3 +600,42 @@ def test_automatic_refresh_pacing_follows_the_drift(oracle, vel_extent, expect_l
             assert c.reorder_interval_in_use >= 48 and c.reorder_count <= 14       # against 27 at a fixed 12
         else:
             assert c.reorder_interval_in_use == 12 and c.reorder_count >= steps // 12 - 1
+
+
+# ---- BASELINE configuration 2 and the switch between the LDS-staged field and the tile order
+
+@pytest.mark.parametrize("n,dims,expect", [
+    (1 << 24, (256, 256, 1), "tile-order"),          # configuration 2: 16M particles, 256 x 256 static field
+    ((1 << 24) - 1, (64, 64, 1), "lds"),             # 64 KiB field, one particle short of the switch: staged in LDS
+    (1 << 24, (64, 64, 1), "tile-order"),            # the same field from 2^24 particles on: tile order
+])
+def test_config2_16m_particles_slices_match_oracle(oracle, n, dims, expect):
+    """Particles generated on the device, swirl field, automatic settings, 26
+    steps = two full refresh cycles of the tile order (scatter at steps 1, 13
+    and 25, counting steps before them); slices of the result against the
+    oracle stepping the same global indices, and the cell indices bit-exact."""
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = dims
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    g = scene_swirl_field(*dims, 10.0, seed=12345)
+    steps = 26
+    with pa.Compute.new(pa.empty_particles(0), g) as c:
+        c.update_sim_params(sp)
+        c.generate_particles(n, seed=12345 + 2, pos_extent=20.0, vel_extent=10.0)
+        if expect == "lds":
+            assert c.reorder_interval_in_use == 0 and c.launch_geometry()["grid_blocks"] == 512
+        else:
+            assert c.reorder_interval_in_use == 12
+        for _ in range(steps):
+            c.compute()
+        assert c.last_step_kernel == pa.KERNEL_STREAM
+        # 3 refreshes at a fixed 12; the automatic pacing may stretch the interval after the first cycle
+        assert (c.reorder_count == 0) if expect == "lds" else (c.reorder_count >= 2)
+        for first in (0, 7654321, n // 2 - 2000, n - 4000):
+            p = oracle.synth_particles(4000, seed=12345 + 2, first_global_index=first, pos_extent=20.0, vel_extent=10.0)
+            want = oracle.run(sp, p, g, steps, mode=oracle.MODE_SKIP_INERT)
+            assert_particles_bit_equal(c.read_particles(first, 4000), want, f"n={n} {dims} slice at {first}")
+            assert np.array_equal(c.debug_cell_indices(first, 4000), oracle.cell_indices(sp, want, g.shape[0]))
+        d = c.diagnostics()
+        assert d["count"] == n
