@@ -55,15 +55,20 @@ def test_powf_path_16_steps(oracle, exponent):
 # The force curves are degree-7 polynomials of the distance, so the same coefficients are 36 times
 # stronger at a cut-off of 2.5 than at 1.5: the third case (two-cell reach) scales them down to stay
 # as gentle as the others (with scale 0.05 there, 16 steps amplify a last-place difference a million
-# times and a third of the particles leave the tolerance, none unexplained).
-@pytest.mark.parametrize("exponent,cutoff,n,scale", [(0.0, 1.5, 6000, 0.05), (0.5, 1.0, 6000, 0.05), (0.0, 2.5, 4000, 0.0015)])
-def test_binned_pair_kernel_16_steps(oracle, exponent, cutoff, n, scale):
+# times and a third of the particles leave the tolerance, none unexplained).  Even so that case has
+# 33 partners per particle and a force that jumps at the cut-off: on the GPU, the binned against the
+# exact kernel (tools/debug/binned_vs_exact.py) stay within 1 ulp of position for 9 steps, at step 10
+# one pair sits on different sides of the cut-off, and its two particles (0.05 off in velocity) pull
+# 40 particles out of tolerance by step 16.  Its budget is therefore 2.5 % instead of 0.5 %.
+@pytest.mark.parametrize("exponent,cutoff,n,scale,budget_div", [
+    (0.0, 1.5, 6000, 0.05, 200), (0.5, 1.0, 6000, 0.05, 200), (0.0, 2.5, 4000, 0.0015, 40)])
+def test_binned_pair_kernel_16_steps(oracle, exponent, cutoff, n, scale, budget_div):
     sp = gentle_pair_params(exponent, cutoff, scale)
     g = sp.new_force_grid_centered().get_force_vectors()
     p = oracle.synth_particles(n, seed=n + 1, pos_extent=20.0, vel_extent=10.0)
     want, direct, tainted = straddlers_on_trajectory(oracle, sp, p, g, K)
     got = run_hip(sp, p, g, pa.PAIRS_BINNED)
-    compare_k_steps(got, want, 2.0 * float(sp.bounding_volume_radius), direct, tainted, budget=n // 200,
+    compare_k_steps(got, want, 2.0 * float(sp.bounding_volume_radius), direct, tainted, budget=n // budget_div,
                     what=f"binned pair kernel, exponent {exponent}, cut-off {cutoff}, {K} steps")
 
 
