@@ -336,6 +336,21 @@ int pcl_diagnostics_read(pcl_compute* h, pcl_diagnostics* out);
  * ordered on the handle's stream: the input of the per-step all-reduce. */
 int pcl_diagnostics_device(pcl_compute* h, void* dev_out);
 
+/* pcl_diagnostics_device for callers that cannot allocate: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  No
+ * counterpart in the reference.  Calls no hipMalloc / hipFree and nothing that
+ * allocates: the reduction's block partials go to a file-scope device array of
+ * the library (196,608 bytes per GPU, held from load until the process ends)
+ * and the 48-byte record is written straight to `dev_out` (8-byte aligned
+ * device memory), asynchronously on the handle's stream.  Always reduces the
+ * latest state (never reuses a fused per-step result), so on the same state it
+ * returns what pcl_diagnostics_device returns when step diagnostics are off.
+ * At most PCL_NOALLOC_MAX_PARTICLES particles (PCL_ERR_INVALID beyond).  All
+ * calls on one GPU share that GPU's array: calls that overlap on one GPU (two
+ * handles on different streams) race; calls on one stream are ordered. */
+#define PCL_NOALLOC_MAX_PARTICLES (1ull << 32)
+int pcl_diagnostics_device_noalloc(pcl_compute* h, void* dev_out);
+
 /* Flat field-cell index of every particle's current position
  * (src/compute.wgsl:81-89,147), for bit-exact index tests. */
 int pcl_debug_cell_indices(pcl_compute* h, uint32_t* out, size_t first, size_t count);

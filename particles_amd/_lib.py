@@ -86,6 +86,7 @@ SIGNATURES = {
     "pcl_pack_particles_device_unordered": (_i, [_vp, _vp]),
     "pcl_diagnostics_read": (_i, [_vp, C.POINTER(Diagnostics)]),
     "pcl_diagnostics_device": (_i, [_vp, _vp]),
+    "pcl_diagnostics_device_noalloc": (_i, [_vp, _vp]),
     "pcl_debug_cell_indices": (_i, [_vp, _vp, _sz, _sz]),
     "pcl_set_stream": (_i, [_vp, _vp]),
     "pcl_use_null_stream": (_i, [_vp]),

@@ -241,6 +241,10 @@ class Compute:
     def diagnostics_device(self, dev_ptr):
         _lib.check(self._lib.pcl_diagnostics_device(self._h, C.c_void_p(int(dev_ptr))))
 
+    def diagnostics_device_noalloc(self, dev_ptr):
+        """``diagnostics_device`` for callers that must not allocate (at most 2^32 particles)."""
+        _lib.check(self._lib.pcl_diagnostics_device_noalloc(self._h, C.c_void_p(int(dev_ptr))))
+
     def enable_step_diagnostics(self, enable=True):
         _lib.check(self._lib.pcl_enable_step_diagnostics(self._h, int(bool(enable))))
 

@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -82,6 +83,24 @@ constexpr size_t kPairSmallSet = size_t(1) << 18;     // up to here the pair ker
 constexpr size_t kArrayStagger = 4096;                // see reserve_particles
 constexpr uint32_t kFoldBlocks = 64;                 // first-level blocks of the diagnostics fold
 
+}  // namespace
+
+// ---- scratch of pcl_diagnostics_device_noalloc ------------------------------
+// One block partial per block of the reduction, in a file-scope device array:
+// every GPU the library runs on holds its own copy (4096 x 48 = 196,608 bytes)
+// from the moment the code object is loaded until the process ends.  In
+// host code the array's name is only a stand-in for the symbol; its address on
+// a device is what hipGetSymbolAddress returns with that device current, taken
+// once per device in pcl_create and kept in g_scratch_ptr.  Every call on a GPU
+// shares that GPU's array: nothing in it needs to start at zero (each launch
+// overwrites the entries it later reads), but two calls that overlap on one
+// GPU (different handles on different streams) race.
+constexpr uint32_t kNoAllocBlocks = 4096;
+static __device__ __align__(256) pcl::DiagPartial scratch[kNoAllocBlocks];
+namespace {
+constexpr int kMaxDevices = 64;
+pcl::DiagPartial* g_scratch_ptr[kMaxDevices] = {nullptr};
+std::mutex g_scratch_mutex;
 }  // namespace
 
 struct pcl_compute {
@@ -1212,6 +1231,16 @@ int pcl_create(const pcl_particle* particles, size_t n, const float (*force_grid
         return fail(PCL_ERR_NO_DEVICE, std::string("pcl_create: device is ") + prop.gcnArchName +
                                            ", this library is built for gfx950 only");
 
+    if (device < kMaxDevices) {
+        // this device's copy of the no-allocation scratch array (the device is current)
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[device]) {
+            pcl::DiagPartial* ptr = nullptr;
+            PCL_HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+            g_scratch_ptr[device] = ptr;
+        }
+    }
+
     pcl_compute* h = new (std::nothrow) pcl_compute();
     if (!h) return fail(PCL_ERR_INVALID, "pcl_create: out of host memory");
     h->device = device;
@@ -1703,6 +1732,28 @@ int pcl_diagnostics_device(pcl_compute* h, void* dev_out)
     PCL_REQUIRE(dev_out != nullptr, "pcl_diagnostics_device: dev_out is null");
     if (int rc = ensure_diag(h)) return rc;
     PCL_HIP_TRY(hipMemcpyAsync(dev_out, h->d_diag, sizeof(pcl_diagnostics), hipMemcpyDeviceToDevice, h->stream));
+    return PCL_OK;
+}
+
+int pcl_diagnostics_device_noalloc(pcl_compute* h, void* dev_out)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_REQUIRE(dev_out != nullptr, "pcl_diagnostics_device_noalloc: dev_out is null");
+    PCL_REQUIRE(reinterpret_cast<uintptr_t>(dev_out) % 8 == 0, "pcl_diagnostics_device_noalloc: dev_out must be 8-byte aligned");
+    PCL_REQUIRE(h->n <= PCL_NOALLOC_MAX_PARTICLES,
+                "pcl_diagnostics_device_noalloc: more than PCL_NOALLOC_MAX_PARTICLES (2^32) particles; use pcl_diagnostics_device");
+    pcl::DiagPartial* ptr = h->device < kMaxDevices ? g_scratch_ptr[h->device] : nullptr;
+    PCL_REQUIRE(ptr != nullptr, "pcl_diagnostics_device_noalloc: no scratch array on this device (device ordinal >= 64)");
+    // the same two launches as ensure_diag, with the block partials in the device's scratch array
+    // and the record written straight to the caller's memory
+    const uint32_t grid = h->n ? std::min<uint32_t>(linear_grid(h, h->n), kNoAllocBlocks) : 1u;
+    hipLaunchKernelGGL(pcl::diag_reduce_kernel, dim3(grid), dim3(pcl::kBlockThreads), 0, h->stream,
+                       soa_of(h, h->cur), cur_ty(h), (unsigned long long)h->n, uniforms_of(h), ptr);
+    PCL_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(pcl::diag_fold_kernel, dim3(1), dim3(pcl::kBlockThreads), 0, h->stream,
+                       (const pcl::DiagPartial*)ptr, grid, grid, (pcl::DiagPartial*)nullptr,
+                       static_cast<pcl::DiagOut*>(dev_out));
+    PCL_HIP_TRY(hipGetLastError());
     return PCL_OK;
 }
 
