@@ -10,10 +10,18 @@ configuration the HBM target is quoted on; seeded synthetic inputs generated
 on the device: pos uniform over the whole bounding cube (worst case for the
 field fetch), vel = 10*(u-0.5), ty = i % 5, masses (1, .5, 2, 1.5, .75), zero
 force curves (the reference's default, so the streaming kernel runs), dt = 1/60.
-For N > 1 this script is started once per GPU by torch.distributed.run; ranks
-own disjoint index ranges, the field is created on rank 0 and replicated with
-one RCCL broadcast, and (with --diagnostics on) the per-step diagnostics are
-all-reduced.  Rank 0 prints one JSON line.
+For N > 1 the script runs once per GPU: started by torch.distributed.run
+(RANK/WORLD_SIZE in the environment), or, when started plainly as
+``python bench.py --gpus N``, it starts torch.distributed.run itself as a child
+process (before anything here touches the GPU) and exits with its status.
+Ranks own disjoint index ranges, the field is created on rank 0 and replicated
+with one RCCL broadcast, and (with --diagnostics on) the per-step diagnostics
+are all-reduced.  Rank 0 prints one JSON line.
+
+Scaling: ``--scaling weak`` (default) keeps --particles-per-gpu per rank;
+``--scaling strong --total-particles T`` splits T over the ranks
+(BASELINE configuration 3: T = 2^28 over 1/2/4/8 GPUs; configuration 4:
+``--gpus 8 --scaling strong --total-particles 1073741824 --diagnostics on``).
 """
 import argparse
 import json
@@ -61,49 +69,75 @@ def make_params(pa, dims):
 
 
 def measured_traffic(n_local, dims, pos_extent):
-    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC
-    passes (profiles/traffic.json), or None when this workload was not profiled."""
+    """HBM bytes per launch of the step kernel: a STORED figure from the committed
+    rocprofv3 PMC passes (profiles/traffic.json, which names the pass files), looked
+    up by workload; None when this workload was not profiled.  Not measured in this run:
+    counters need rocprofv3 around the process."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             table = json.load(f)
         rec = table.get(f"{n_local}|{dims[0]}x{dims[1]}x{dims[2]}|{float(pos_extent)}")
-        return rec["hbm_bytes"] if rec else None
+        return (rec["hbm_bytes"], rec.get("source")) if rec else (None, None)
     except (OSError, ValueError, KeyError):
-        return None
+        return None, None
 
 
 def cpu_baseline(sp, field, seed, pos_extent, budget_s=12.0):
     """Time the CPU oracle (scalar C restatement of the shader, same pair-skip
     rule, index-range split over host threads) on a bounded sample of the same
-    workload."""
+    workload: 2^24 particles for about `budget_s` seconds on every core this
+    process may use, plus quick points at 2^20 particles and on one thread."""
     from oracle import oracle as O
-    threads = max(1, min(16, O.max_threads(), os.cpu_count() or 1))
-    n = 1 << 22
-    p = O.synth_particles(n, seed, 0, pos_extent, 10.0)
-    O.step(sp, p, field, mode=O.MODE_SKIP_INERT, threads=threads)  # warm-up
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        p = O.step(sp, p, field, mode=O.MODE_SKIP_INERT, threads=threads)
-        steps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or steps >= 256:
-            break
-    # single-thread point on a quarter of the sample
-    q = p[: n // 4].copy()
-    t1 = time.perf_counter()
-    for _ in range(2):
-        q = O.step(sp, q, field, mode=O.MODE_SKIP_INERT, threads=1)
-    single = (n // 4) * 2 / (time.perf_counter() - t1)
+    nproc = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = nproc
+    # OpenMP's own limit (OMP_NUM_THREADS, which the GPU boxes set to their CPU share) and the affinity mask
+    threads = max(1, min(O.max_threads(), usable))
+
+    def rate(n, thr, budget, max_steps):
+        p = O.synth_particles(n, seed, 0, pos_extent, 10.0)
+        p = O.step(sp, p, field, mode=O.MODE_SKIP_INERT, threads=thr)   # warm-up
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            p = O.step(sp, p, field, mode=O.MODE_SKIP_INERT, threads=thr)
+            steps += 1
+            el = time.perf_counter() - t0
+            if el >= budget or steps >= max_steps:
+                return n * steps / el, steps, el
+
+    n = 1 << 24
+    value, steps, el = rate(n, threads, budget_s, 256)
+    small, _, _ = rate(1 << 20, threads, 1.5, 64)
+    single, _, _ = rate(1 << 20, 1, 1.5, 8)
     return {
-        "value": n * steps / el,
+        "value": value,
         "unit": "particle-steps/s",
         "cores": threads,
         "kind": "port",
         "sample": f"{steps} steps of {n} particles (same field, params and distributions), "
-                  f"C oracle -O3, {threads} OpenMP threads, {el:.1f} s; "
-                  f"one thread: {single:.3g} particle-steps/s; host has {os.cpu_count()} logical CPUs",
+                  f"C oracle -O3, {threads} OpenMP threads, {el:.1f} s; 2^20 particles on {threads} threads: "
+                  f"{small:.3g} particle-steps/s; 2^20 on one thread: {single:.3g}; "
+                  f"nproc {nproc}, usable by this process {usable}, OMP_NUM_THREADS={os.environ.get('OMP_NUM_THREADS', 'unset')}",
+        "nproc": nproc,
+        "value_2p20": small,
         "single_thread_value": single,
     }
+
+
+def self_launch(n_ranks, argv):
+    """``python bench.py --gpus N`` without a launcher: start N ranks through
+    torch.distributed.run as a child process.  This process has not imported
+    torch or touched the GPU; it only waits and passes the child's status on."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd)
 
 
 def main():
@@ -112,6 +146,10 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--particles-per-gpu", type=int, default=1 << 28)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --particles-per-gpu on every rank; strong: --total-particles split over the ranks")
+    ap.add_argument("--total-particles", type=int, default=1 << 28,
+                    help="strong scaling only: the whole set (2^28 = configuration 3, 2^30 over 8 GPUs = configuration 4)")
     ap.add_argument("--field", type=int, nargs=3, default=(1024, 1024, 1), metavar=("NX", "NY", "NZ"))
     ap.add_argument("--pos-extent", type=float, default=2.0 * RADIUS,
                     help="positions are pos_extent*(u-0.5); 20 = whole cube, 2 = the reference's cluster")
@@ -139,6 +177,9 @@ def main():
                     help="use the RCCL broadcast/all-reduce path even with one rank (when started by torch.distributed.run)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+
     # stdout carries exactly one JSON line: anything libraries print there (RCCL's version banner)
     # goes to stderr instead
     sys.stdout.flush()
@@ -153,7 +194,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus disagree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     device_index = local_rank % torch.cuda.device_count()   # one GPU per rank; wraps only in a gloo rehearsal
@@ -169,16 +210,17 @@ def main():
 
     dims = tuple(args.field)
     n_cells = dims[0] * dims[1] * dims[2]
-    n_local = args.particles_per_gpu
+    n_total = args.total_particles if args.scaling == "strong" else args.particles_per_gpu * world
     sp = make_params(pa, dims)
 
     # Field: built on rank 0, replicated by ShardedCompute with one broadcast over RCCL;
     # every rank fills its own index range with the seeded scene on the device.
     field_host = swirl_field(*dims, RADIUS, args.seed) if rank == 0 else None
-    sc = pa.ShardedCompute.new(None, field_host, n_total=n_local * world, seed=args.seed,
+    sc = pa.ShardedCompute.new(None, field_host, n_total=n_total, seed=args.seed,
                                pos_extent=args.pos_extent, vel_extent=args.vel_extent, device=device_index,
                                force_collectives=args.force_collectives)
-    assert sc.num_local_particles == n_local
+    n_local = sc.num_local_particles        # this rank's index range [g*N/G, (g+1)*N/G)
+    assert args.scaling == "strong" or n_local == args.particles_per_gpu
     c = sc.local
     c.set_tuning(args.grid_blocks, args.variant)
     c.set_reorder_interval(args.reorder_interval)
@@ -231,10 +273,16 @@ def main():
                for k, name in ((1, "step_stream_kernel"), (2, "step_pairs_kernel"),
                                (3, "step_stream_kernel+count"), (4, "step_scatter_kernel"))}
 
+    kernel_ms_local = kernel_ms
+    per_rank_kernel_ms = [kernel_ms]
     if dist.is_initialized():
         t = torch.tensor([elapsed, kernel_ms, region_ms], dtype=torch.float64, device=reduce_device)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank_kernel_ms = [float(e[1]) for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms, region_ms = float(t[0]), float(t[1]), float(t[2])
+    rccl_ranks = dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0
 
     # Beside the headline (one launch per step): the same update through pcl_step_n, which fuses
     # runs of steps into single launches for callers that do not need the intermediate states.
@@ -250,7 +298,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             fused_ms = float(t[0])
         fused = {"steps": args.fused_steps, "ms_per_step": fused_ms,
-                 "value": n_local * world / (fused_ms * 1e-3), "unit": "particle-steps/s",
+                 "value": n_total / (fused_ms * 1e-3), "unit": "particle-steps/s",
                  "note": "NOT the headline: pcl_step_n keeps the particles in registers over runs of up to 16 "
                          "steps (49 B of HBM traffic per particle per launch instead of per step); results are "
                          "bit-identical to single steps, intermediate states are not materialised"}
@@ -260,9 +308,36 @@ def main():
     kernel = c.last_step_kernel
 
     if rank == 0:
-        total = n_local * world
+        total = n_total
         value = total * args.steps / elapsed
-        achieved = n_local * BYTES_PER_PARTICLE_STEP / (kernel_ms * 1e-3) / 1e9
+        # rank 0's own launches over rank 0's own range
+        achieved = n_local * BYTES_PER_PARTICLE_STEP / (kernel_ms_local * 1e-3) / 1e9
+        whole = n_local * BYTES_PER_PARTICLE_STEP / (region_ms * 1e-3) / 1e9
+        if args.scaling == "strong" and total == 1 << 28 and dims == (1024, 1024, 1):
+            which = "BASELINE configuration 3 (256M particles, 1024x1024 field, particle-sharded)"
+        elif args.scaling == "strong" and total == 1 << 30 and dims == (1024, 1024, 1) and diag_on:
+            which = "BASELINE configuration 4 (1B particles, diagnostics all-reduce per step)"
+        elif world == 1 and total == 1 << 28 and dims == (1024, 1024, 1):
+            which = "BASELINE configuration 3 at one GPU (256M particles, 1024x1024 field)"
+        elif world == 1 and total == 1 << 24 and dims == (256, 256, 1):
+            which = "BASELINE configuration 2 (16M particles, 256x256 field)"
+        elif total == 1 << 26 and args.edits:
+            which = "BASELINE configuration 5 (64M particles, per-frame brush edits)"
+        elif args.scaling == "weak" and args.particles_per_gpu == 1 << 28 and dims == (1024, 1024, 1):
+            which = "configuration 3's per-GPU load on every GPU (weak scaling: 2^28 particles per GPU)"
+        else:
+            which = "custom"
+        # the launches that also refresh the particle order move more bytes per particle:
+        # counting step 49 B (same traffic, extra LDS histogram), scatter step 49 B + 4 B index read + 4 B index write + 1 B type write
+        kernel_rooflines = []
+        for k, name, nbytes in ((1, "step_stream_kernel", 49), (2, "step_pairs_kernel", 49),
+                                (3, "step_stream_kernel+count", 49), (4, "step_scatter_kernel", 58)):
+            ms = by_kind[name]["avg_ms"]
+            if ms:
+                a = n_local * nbytes / (ms * 1e-3) / 1e9
+                kernel_rooflines.append({"kernel": name, "launches": by_kind[name]["launches"], "avg_ms": ms,
+                                         "bytes_per_particle": nbytes, "achieved": a, "frac": a / HBM_PEAK_GBS})
+        traffic, traffic_source = measured_traffic(n_local, dims, args.pos_extent) if args.vel_extent == 10.0 else (None, None)
         out = {
             "metric": "particle-steps/sec",
             "value": value,
@@ -272,14 +347,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "rccl_ranks": rccl_ranks,
+            "kernel_ms_per_rank": {"min": min(per_rank_kernel_ms), "max": max(per_rank_kernel_ms)},
             "config": {
-                "workload": f"{n_local} particles per GPU ({total} total), "
+                "workload": f"{which}: {n_local} particles on rank 0's GPU ({total} total over {world}), "
                             f"{dims[0]}x{dims[1]}x{dims[2]} static vector field, fp32 SoA, pair term inert",
                 "particles_per_gpu": n_local,
+                "total_particles": total,
                 "field_dims": list(dims),
                 "pos_extent": args.pos_extent,
                 "vel_extent": args.vel_extent,
@@ -298,18 +376,21 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(n_local, dims, args.pos_extent) if args.vel_extent == 10.0 else None,
+                "traffic": traffic,
+                "traffic_source": (f"stored figure from rocprofv3 PMC passes, {traffic_source or 'profiles/traffic.json'}; "
+                                   "not measured in this run") if traffic else None,
+                "whole_step_frac": whole / HBM_PEAK_GBS,
                 "bytes_per_particle_step": BYTES_PER_PARTICLE_STEP,
                 "kernel": {1: "step_stream_kernel", 2: "step_pairs_kernel"}.get(kernel, "none"),
-                "kernel_ms": kernel_ms,
+                "kernel_ms": kernel_ms_local,
+                "kernels": kernel_rooflines,
                 "launches_by_kind": by_kind,
-                "whole_region": {"ms_per_step": region_ms,
-                                 "achieved": n_local * BYTES_PER_PARTICLE_STEP / (region_ms * 1e-3) / 1e9,
-                                 "frac": n_local * BYTES_PER_PARTICLE_STEP / (region_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "whole_region": {"ms_per_step": region_ms, "achieved": whole, "frac": whole / HBM_PEAK_GBS},
                 "note": "achieved/frac: algorithmic bytes per launch / average launch duration of the dominant kernel "
-                        "(HIP event pair per launch on the kernel's stream, rank 0). whole_region: the same bytes "
-                        "over the HIP-event time of the whole timed region / steps, i.e. including the counting and "
-                        "scatter launches that refresh the particle order",
+                        "(HIP event pair per launch on the kernel's stream, rank 0). whole_step_frac / whole_region: "
+                        "49 B per particle over the HIP-event time of the whole timed region / steps, i.e. including "
+                        "the counting and scatter launches that refresh the particle order. kernels: every launch "
+                        "kind of the timed region with its own byte count",
             },
             "final_diagnostics": {"count": diag["count"], "kinetic_energy": diag["kinetic_energy"]},
         }
@@ -317,6 +398,7 @@ def main():
             out["fused_stepping"] = fused
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sp, field_host, args.seed, args.pos_extent)
+            out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 

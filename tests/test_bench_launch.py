@@ -1,0 +1,74 @@
+"""``python bench.py --gpus N`` started plainly (no torch.distributed.run, no
+RANK/WORLD_SIZE in the environment) starts its own ranks.  On the CPU the ranks
+come up and stop at bench.py's "needs a GPU" check (there is no CPU fallback);
+on a GPU box two ranks share the one GPU over gloo and rank 0 prints exactly one
+JSON line; with two or more GPUs the same runs over RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _plain_env():
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return env
+
+
+def test_plain_start_with_two_gpus_launches_two_ranks_cpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU check of the launcher; the GPU tests below run the whole thing")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--particles-per-gpu", "4096", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=_plain_env())
+    # both ranks were started (by torch.distributed.run as a child) and both refused to run without a GPU
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
+    assert r.stdout.strip() == ""
+
+
+def _run_and_parse(extra, timeout=600):
+    r = subprocess.run([sys.executable, BENCH] + extra, capture_output=True, text=True, timeout=timeout, env=_plain_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_plain_start_two_ranks_one_gpu_over_gloo():
+    out = _run_and_parse(["--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2",
+                          "--particles-per-gpu", str(1 << 20), "--field", "256", "256", "1",
+                          "--diagnostics", "on", "--no-cpu-baseline", "--fused-steps", "0"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["rccl_ranks"] == 0
+    assert out["config"]["total_particles"] == 2 << 20
+    assert out["final_diagnostics"]["count"] == 2 << 20          # the all-reduce saw both ranks
+    assert out["kernel_ms_per_rank"]["min"] > 0
+
+
+@pytest.mark.gpu
+def test_strong_scaling_splits_the_total():
+    out = _run_and_parse(["--gpus", "2", "--backend", "gloo", "--steps", "4", "--warmup", "1", "--scaling", "strong",
+                          "--total-particles", str((1 << 21) + 1), "--field", "256", "256", "1",
+                          "--no-cpu-baseline", "--fused-steps", "0"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["particles_per_gpu"] == 1 << 20           # rank 0's range [0, N/2)
+    assert out["final_diagnostics"]["count"] == (1 << 21) + 1
+
+
+@pytest.mark.gpu
+def test_plain_start_two_ranks_over_rccl():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank; this box has one")
+    out = _run_and_parse(["--gpus", "2", "--steps", "6", "--warmup", "2", "--particles-per-gpu", str(1 << 22),
+                          "--diagnostics", "on", "--no-cpu-baseline", "--fused-steps", "0"])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2
+    assert out["final_diagnostics"]["count"] == 2 << 22

@@ -54,20 +54,28 @@ def _brush(pa):
     return pa.EditMode(mode="rotate", relative=False, falloff="linear", falloff_dist=2.0, strength=1.5)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, backend="gloo"):
     sys.path.insert(0, os.path.dirname(HERE))
+    import torch
     import torch.distributed as dist
     import particles_amd as pa
     from oracle import oracle as O
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    device = 0
+    if backend == "nccl":            # RCCL: one GPU per rank
+        device = rank
+        torch.cuda.set_device(device)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         sp, g = _scene(pa, O)
         # every rank generates its own range on the device; the field comes from rank 0
         sc = pa.ShardedCompute.new(None, g if rank == 0 else None, n_total=N, seed=31, pos_extent=20.0,
-                                   vel_extent=10.0, device=0)
+                                   vel_extent=10.0, device=device)
         assert type(sc.local) is pa.Compute and (sc.first, sc.last) == pa.shard_range(N, rank, world)
         sc.local.set_reorder_interval(3)            # tile order inside every range
         sc.update_sim_params(sp)
@@ -97,7 +105,8 @@ def _worker(rank, world, port, out_dir):
         pairs = sc.gather_particles()
         # two particles over three ranks: rank 0's range is empty, it still takes part in everything
         sc.upload_particles(p[:2])
-        assert sc.num_local_particles == (0, 1, 1)[rank]
+        first, last = pa.shard_range(2, rank, world)
+        assert sc.num_local_particles == last - first and (world != 3 or sc.num_local_particles == (0, 1, 1)[rank])
         sc.compute()
         sparse = sc.gather_particles()
         sparse_count = sc.diagnostics()["count"]
@@ -111,10 +120,25 @@ def _worker(rank, world, port, out_dir):
 
 
 def test_three_ranks_on_one_gpu_match_the_unsharded_oracle(tmp_path, oracle):
+    _run_and_compare(tmp_path, oracle, WORLD, "gloo")
+
+
+def test_two_ranks_over_rccl_match_the_unsharded_oracle(tmp_path, oracle):
+    """The same script with one GPU per rank and every collective over RCCL
+    (field and cursor-record broadcasts, diagnostics all-reduces, the pair
+    term's all-gather, all ordered against the kernels on the device's null
+    stream).  Needs two GPUs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank; this box has one")
+    _run_and_compare(tmp_path, oracle, 2, "nccl")
+
+
+def _run_and_compare(tmp_path, oracle, world, backend):
     import particles_amd as pa
     sys.path.insert(0, HERE)
     from oracle_backend import OracleCompute
-    mp.spawn(_worker, args=(WORLD, _free_port(), str(tmp_path)), nprocs=WORLD, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), backend), nprocs=world, join=True)
 
     sp, g = _scene(pa, oracle)
     model = OracleCompute.new(oracle.synth_particles(N, seed=31, pos_extent=20.0, vel_extent=10.0), g)
@@ -141,7 +165,7 @@ def test_three_ranks_on_one_gpu_match_the_unsharded_oracle(tmp_path, oracle):
     want_sparse = model.read_particles()
     assert not np.array_equal(want_field, g)                      # the brush did change cells
 
-    for rank in range(WORLD):
+    for rank in range(world):
         r = np.load(tmp_path / f"rank{rank}.npz")
         assert r["stream"].tobytes() == want_stream.tobytes(), f"rank {rank}: streaming path"
         assert r["field"].tobytes() == want_field.tobytes(), f"rank {rank}: field after the brush"
