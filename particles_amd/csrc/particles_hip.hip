@@ -867,7 +867,12 @@ int do_step_impl(pcl_compute* h, int* kind)
             }
             if (h->step_diag)
                 if (int rc = reserve_partials(h, grid)) return rc;
-            const int src = h->cur, dst = h->cur ^ 1;
+            // In place: every lane reads its particles before it writes them and no lane reads
+            // another's, so the update may overwrite its input (tuning bit 0x80000; measured: 0.3 %
+            // faster than the ping-pong, within the noise, so the ping-pong stays the default).
+            const bool in_place = (h->variant & 0x80000u) != 0;
+            const int src = h->cur, dst = in_place ? h->cur : (h->cur ^ 1);
+            if (in_place) flipped = true;   // state[cur] stays the current buffer
             pcl::StreamArgs a;
             for (int k = 0; k < 6; ++k) { a.src[k] = h->state[src][k]; a.dst[k] = h->state[dst][k]; }
             a.ty = cur_ty(h);

@@ -319,8 +319,8 @@ __device__ __forceinline__ uint32_t lds_rank_add(uint32_t* counters, uint32_t ke
 }
 
 struct StreamArgs {
-    const float* __restrict__ src[6];
-    float* __restrict__ dst[6];
+    const float* src[6];   // dst may equal src (in-place update): no __restrict__ on the state arrays
+    float* dst[6];
     const uint8_t* __restrict__ ty;
     const f32x4* __restrict__ field;
     unsigned long long n;
