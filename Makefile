@@ -9,7 +9,9 @@ LIB       := particles_amd/libparticles_hip.so
 SRC       := particles_amd/csrc/particles_hip.hip
 SORT_SRC  := particles_amd/csrc/pair_sort.hip
 SORT_OBJ  := build/pair_sort.o
-HDRS      := particles_amd/csrc/step_kernels.hpp particles_amd/csrc/reorder_kernels.hpp particles_amd/csrc/brush_kernels.hpp include/particles_hip.h
+HDRS      := particles_amd/csrc/step_kernels.hpp particles_amd/csrc/reorder_kernels.hpp particles_amd/csrc/brush_kernels.hpp particles_amd/csrc/handle_access.hpp include/particles_hip.h
+COMM_SRC  := particles_amd/csrc/particles_comm.hip
+COMM_OBJ  := build/particles_comm.o
 
 CPPTEST   := tests/cpp/compute_wrapper_test
 
@@ -25,8 +27,13 @@ $(MAIN_OBJ): $(SRC) $(HDRS)
 	mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $(SRC)
 
-$(LIB): $(MAIN_OBJ) $(SORT_OBJ)
-	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $(MAIN_OBJ) $(SORT_OBJ)
+# the multi-GPU layer; RCCL itself is loaded at run time (dlopen), only its header is needed here
+$(COMM_OBJ): $(COMM_SRC) $(HDRS)
+	mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $(COMM_SRC)
+
+$(LIB): $(MAIN_OBJ) $(SORT_OBJ) $(COMM_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $(MAIN_OBJ) $(SORT_OBJ) $(COMM_OBJ) -ldl
 
 oracle:
 	$(MAKE) -C oracle

@@ -173,6 +173,9 @@ def main():
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="process-group backend: nccl is RCCL over xGMI; gloo stages every collective through the host "
                          "and admits several ranks on one GPU (a rehearsal of the multi-rank path on a one-GPU box)")
+    ap.add_argument("--collectives", choices=("torch", "native"), default="torch",
+                    help="torch: torch.distributed calls (backend nccl is RCCL); native: RCCL called inside the library "
+                         "on the handle's own stream (pcl_comm_*), the process group only carries the unique id")
     ap.add_argument("--force-collectives", action="store_true",
                     help="use the RCCL broadcast/all-reduce path even with one rank (when started by torch.distributed.run)")
     args = ap.parse_args()
@@ -218,7 +221,7 @@ def main():
     field_host = swirl_field(*dims, RADIUS, args.seed) if rank == 0 else None
     sc = pa.ShardedCompute.new(None, field_host, n_total=n_total, seed=args.seed,
                                pos_extent=args.pos_extent, vel_extent=args.vel_extent, device=device_index,
-                               force_collectives=args.force_collectives)
+                               force_collectives=args.force_collectives, collectives=args.collectives, n_cells=n_cells)
     n_local = sc.num_local_particles        # this rank's index range [g*N/G, (g+1)*N/G)
     assert args.scaling == "strong" or n_local == args.particles_per_gpu
     c = sc.local
@@ -282,7 +285,10 @@ def main():
         per_rank_kernel_ms = [float(e[1]) for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms, region_ms = float(t[0]), float(t[1]), float(t[2])
-    rccl_ranks = dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0
+    if args.collectives == "native":
+        rccl_ranks = int(c._lib.pcl_comm_world(c._h))        # the library's own communicator
+    else:
+        rccl_ranks = dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0
 
     # Beside the headline (one launch per step): the same update through pcl_step_n, which fuses
     # runs of steps into single launches for callers that do not need the intermediate states.
@@ -366,7 +372,8 @@ def main():
                 "reorder_interval": args.reorder_interval,
                 "reorder_passes_in_timed_region": reorders_timed,
                 "parallelism": f"particle-sharded x{world}, field replicated by "
-                               + ("RCCL broadcast" if args.backend == "nccl" else "gloo broadcast (host-staged rehearsal)"),
+                               + ("RCCL broadcast inside the library" if args.collectives == "native" else
+                                  "RCCL broadcast" if args.backend == "nccl" else "gloo broadcast (host-staged rehearsal)"),
                 "kernel": {1: "step_stream_kernel", 2: "step_pairs_kernel"}.get(kernel, "none"),
                 "launch": geometry,
             },

@@ -85,11 +85,12 @@ enum {
     PCL_ERR_HIP          = -2, /* a HIP runtime call failed; see pcl_last_error()          */
     PCL_ERR_NO_DEVICE    = -3, /* no usable gfx950 device                                  */
     PCL_ERR_OUT_OF_RANGE = -4, /* first/count outside the particle or cell range           */
-    PCL_ERR_DEVICE       = -5  /* a kernel of the handle flagged a condition only it could see (the order refresh
+    PCL_ERR_DEVICE       = -5, /* a kernel of the handle flagged a condition only it could see (the order refresh
                                   reserved more slots than its histogram counted; a cursor record read from device
                                   memory had an unknown mode or falloff).  Returned once, by the next call that
                                   synchronises the stream (pcl_synchronize, pcl_read_*, pcl_diagnostics_read,
                                   pcl_debug_cell_indices, pcl_brush_selection); pcl_last_error() says which */
+    PCL_ERR_COMM         = -6  /* RCCL could not be loaded, or one of its calls failed                           */
 };
 
 /* Which kernel family pcl_step picked (see pcl_last_step_kernel). */
@@ -436,6 +437,94 @@ int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks,
  *   0x40000  tests only: the next refresh of the particle order scatters with other keys than its
  *            histogram counted, which the kernel reports as PCL_ERR_DEVICE (the state is then unusable) */
 int pcl_set_tuning(pcl_compute* h, uint32_t grid_blocks, uint32_t variant);
+
+/* ======================================================================
+ * Several GPUs of one node (RCCL over xGMI inside the library).
+ *
+ * No counterpart in the reference, which runs on one device: a host would
+ * change its construction (src/main.rs:232-236) and its per-frame calls
+ * (src/main.rs:371-390, src/renderer.rs:225).  Particles shard by contiguous
+ * index range, rank g of G holding [g*N/G, (g+1)*N/G); the field and the
+ * parameter block are replicated.  With the pair term inert
+ * (src/compute.wgsl:115-144 adds nothing) a step involves no collective on
+ * the data path.  What travels: the field (or its dirty range, or a brush's
+ * 64-byte cursor record) by ncclBroadcast into every replica; with the pair
+ * term active, one ncclAllGather of 16 bytes per particle per step; with step
+ * diagnostics on, one ncclGroupStart/End pair of all-reduces of the 48-byte
+ * record per step.  Every collective runs on the handle's own stream, ordered
+ * with its kernels.  RCCL is loaded at first use (dlopen; PCL_RCCL_LIBRARY
+ * names the file when the default search is not wanted); without it these
+ * calls return PCL_ERR_COMM and the rest of the library works.
+ *
+ * Two ways to form the communicator:
+ *   pcl_comm_*  : one process (or thread) per GPU.  Rank 0 makes a unique id,
+ *                 the host carries its 128 bytes to the other ranks by any
+ *                 means, every rank attaches its own handle.  The pcl_comm_*
+ *                 calls below are collective: every rank makes the same call,
+ *                 in the same order, with the same sizes and root; pointers
+ *                 to host data are only looked at on the root.
+ *   pcl_group_* : one process holds a handle per GPU (ncclCommInitAll) and
+ *                 every call works on all of them, rank 0 being the root.
+ * ====================================================================== */
+
+#define PCL_UNIQUE_ID_BYTES 128
+int pcl_comm_unique_id(void* out_id /* PCL_UNIQUE_ID_BYTES */);
+int pcl_comm_attach(pcl_compute* h, const void* unique_id, int rank, int world);
+int pcl_comm_detach(pcl_compute* h);          /* pcl_destroy does it too */
+int pcl_comm_rank(const pcl_compute* h);      /* -1 without a communicator */
+int pcl_comm_world(const pcl_compute* h);     /*  0 without a communicator */
+
+/* Compute::update_force_grid (src/compute.rs:198-204) on every replica: the
+ * root's cells are broadcast straight into each handle's field. */
+int pcl_comm_update_force_grid(pcl_compute* h, const float (*force_grid)[4], size_t n_cells, int root);
+/* Brush edits (src/main.rs:371-380 uploads the whole field instead): only the
+ * dirty range, or only the listed cells (20 bytes each), travel. */
+int pcl_comm_patch_force_grid(pcl_compute* h, size_t first_cell, const float (*cells)[4], size_t count, int root);
+int pcl_comm_patch_force_grid_indexed(pcl_compute* h, const uint32_t* cell_indices, const float (*cells)[4],
+                                      size_t count, int root);
+/* Cursor::mouse_down / mouse_moved (src/cursor.rs:79-116) on every replica:
+ * the root's 64-byte record is broadcast and each GPU edits its own field. */
+int pcl_comm_brush_mouse_down(pcl_compute* h, const pcl_brush_input* in, int root);
+int pcl_comm_brush_mouse_moved(pcl_compute* h, const pcl_brush_input* in, int root);
+/* Compute::compute (src/compute.rs:221-227) of this rank's range.  Pair term
+ * active: all ranks exchange positions and types first (all-gather) and every
+ * particle sums over all of them in global index order, which gives the bits
+ * of one handle holding every particle under PCL_PAIRS_ALL.  Step diagnostics
+ * enabled: also starts the all-reduce of the record (asynchronous; the result
+ * is what pcl_comm_diagnostics_device points at). */
+int pcl_comm_step(pcl_compute* h);
+/* Diagnostics of the latest state of ALL ranges, identical on every rank. */
+int pcl_comm_diagnostics_read(pcl_compute* h, pcl_diagnostics* out);
+int pcl_comm_diagnostics_device(pcl_compute* h, const void** dev_record);
+
+typedef struct pcl_group pcl_group; /* one handle per GPU, driven by one process */
+
+/* Compute::new (src/compute.rs:25) over `n_devices` GPUs: particle i goes to
+ * the handle whose range holds i, the field to all of them. */
+int pcl_group_create(const int* devices, int n_devices, const pcl_particle* particles, size_t n,
+                     const float (*force_grid)[4], size_t n_cells, pcl_group** out);
+int pcl_group_destroy(pcl_group* g);
+int pcl_group_size(const pcl_group* g);
+pcl_compute* pcl_group_handle(pcl_group* g, int i);   /* for per-GPU settings and reads; owned by the group */
+size_t pcl_group_num_particles(const pcl_group* g);   /* the whole set */
+int pcl_group_upload_particles(pcl_group* g, const pcl_particle* particles, size_t n);
+/* pcl_generate_particles for the whole set: every GPU fills its own range. */
+int pcl_group_generate_particles(pcl_group* g, size_t n_total, uint64_t seed, float pos_extent, float vel_extent);
+int pcl_group_update_force_grid(pcl_group* g, const float (*force_grid)[4], size_t n_cells);
+int pcl_group_patch_force_grid(pcl_group* g, size_t first_cell, const float (*cells)[4], size_t count);
+int pcl_group_patch_force_grid_indexed(pcl_group* g, const uint32_t* cell_indices, const float (*cells)[4], size_t count);
+int pcl_group_update_sim_params(pcl_group* g, const pcl_sim_params* params);
+int pcl_group_enable_step_diagnostics(pcl_group* g, int enable);
+int pcl_group_step(pcl_group* g);
+int pcl_group_brush_mouse_down(pcl_group* g, const pcl_brush_input* in);
+int pcl_group_brush_mouse_moved(pcl_group* g, const pcl_brush_input* in);
+int pcl_group_brush_mouse_up(pcl_group* g);
+int pcl_group_diagnostics_read(pcl_group* g, pcl_diagnostics* out);
+/* Records [first, first + count) of the whole set, caller order. */
+int pcl_group_read_particles(pcl_group* g, pcl_particle* out, size_t first, size_t count);
+/* Cells of one replica of the field (they are all equal). */
+int pcl_group_read_force_grid(pcl_group* g, int replica, float (*out)[4], size_t first_cell, size_t count);
+int pcl_group_synchronize(pcl_group* g);
 
 #ifdef __cplusplus
 } /* extern "C" */

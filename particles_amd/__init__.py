@@ -13,6 +13,7 @@ from ._lib import (STEP_NONE, STEP_STREAM, STEP_PAIRS, STEP_STREAM_COUNT, STEP_S
 from .compute import Compute
 from .cursor import BRUSH_INPUT_DTYPE, Brush, DeviceBrush, EditMode
 from .sharded import ShardedCompute, shard_range
+from .group import Group
 
 __all__ = [
     "PARTICLE_DTYPE", "MASS_WRAP_DTYPE", "NUM_TYPES", "empty_particles", "lattice_particles", "random_particles",
@@ -20,5 +21,5 @@ __all__ = [
     "STEP_NONE", "STEP_STREAM", "STEP_PAIRS", "STEP_STREAM_COUNT", "STEP_STREAM_SCATTER", "STEP_PAIRS_BINNED",
     "STEP_PAIRS_GATHERED", "STEP_STREAM_FUSED",
     "PAIRS_AUTO", "PAIRS_ALL", "PAIRS_BINNED",
-    "PclError", "KERNEL_NONE", "KERNEL_STREAM", "KERNEL_PAIRS", "Compute", "ShardedCompute", "shard_range", "Brush", "DeviceBrush", "EditMode", "BRUSH_INPUT_DTYPE",
+    "PclError", "KERNEL_NONE", "KERNEL_STREAM", "KERNEL_PAIRS", "Compute", "Group", "ShardedCompute", "shard_range", "Brush", "DeviceBrush", "EditMode", "BRUSH_INPUT_DTYPE",
 ]

@@ -15,6 +15,8 @@ PCL_ERR_HIP = -2
 PCL_ERR_NO_DEVICE = -3
 PCL_ERR_OUT_OF_RANGE = -4
 PCL_ERR_DEVICE = -5
+PCL_ERR_COMM = -6
+UNIQUE_ID_BYTES = 128
 
 KERNEL_NONE, KERNEL_STREAM, KERNEL_PAIRS = 0, 1, 2
 STEP_NONE, STEP_STREAM, STEP_PAIRS, STEP_STREAM_COUNT, STEP_STREAM_SCATTER, STEP_PAIRS_BINNED = 0, 1, 2, 3, 4, 5
@@ -101,6 +103,40 @@ SIGNATURES = {
     "pcl_reorder_now": (_i, [_vp]),
     "pcl_reorder_count": (_u64, [_vp]),
     "pcl_set_tuning": (_i, [_vp, _u32, _u32]),
+    # several GPUs: RCCL inside the library
+    "pcl_comm_unique_id": (_i, [_vp]),
+    "pcl_comm_attach": (_i, [_vp, _vp, _i, _i]),
+    "pcl_comm_detach": (_i, [_vp]),
+    "pcl_comm_rank": (_i, [_vp]),
+    "pcl_comm_world": (_i, [_vp]),
+    "pcl_comm_update_force_grid": (_i, [_vp, _vp, _sz, _i]),
+    "pcl_comm_patch_force_grid": (_i, [_vp, _sz, _vp, _sz, _i]),
+    "pcl_comm_patch_force_grid_indexed": (_i, [_vp, _vp, _vp, _sz, _i]),
+    "pcl_comm_brush_mouse_down": (_i, [_vp, _vp, _i]),
+    "pcl_comm_brush_mouse_moved": (_i, [_vp, _vp, _i]),
+    "pcl_comm_step": (_i, [_vp]),
+    "pcl_comm_diagnostics_read": (_i, [_vp, C.POINTER(Diagnostics)]),
+    "pcl_comm_diagnostics_device": (_i, [_vp, C.POINTER(_vp)]),
+    "pcl_group_create": (_i, [_vp, _i, _vp, _sz, _vp, _sz, C.POINTER(_vp)]),
+    "pcl_group_destroy": (_i, [_vp]),
+    "pcl_group_size": (_i, [_vp]),
+    "pcl_group_handle": (_vp, [_vp, _i]),
+    "pcl_group_num_particles": (_sz, [_vp]),
+    "pcl_group_upload_particles": (_i, [_vp, _vp, _sz]),
+    "pcl_group_generate_particles": (_i, [_vp, _sz, _u64, _f, _f]),
+    "pcl_group_update_force_grid": (_i, [_vp, _vp, _sz]),
+    "pcl_group_patch_force_grid": (_i, [_vp, _sz, _vp, _sz]),
+    "pcl_group_patch_force_grid_indexed": (_i, [_vp, _vp, _vp, _sz]),
+    "pcl_group_update_sim_params": (_i, [_vp, _vp]),
+    "pcl_group_enable_step_diagnostics": (_i, [_vp, _i]),
+    "pcl_group_step": (_i, [_vp]),
+    "pcl_group_brush_mouse_down": (_i, [_vp, _vp]),
+    "pcl_group_brush_mouse_moved": (_i, [_vp, _vp]),
+    "pcl_group_brush_mouse_up": (_i, [_vp]),
+    "pcl_group_diagnostics_read": (_i, [_vp, C.POINTER(Diagnostics)]),
+    "pcl_group_read_particles": (_i, [_vp, _vp, _sz, _sz]),
+    "pcl_group_read_force_grid": (_i, [_vp, _i, _vp, _sz, _sz]),
+    "pcl_group_synchronize": (_i, [_vp]),
 }
 
 _lib = None
@@ -117,9 +153,15 @@ def _share_torch_hip_runtime():
     spec = importlib.util.find_spec("torch")
     if spec is None or not spec.submodule_search_locations:
         return
-    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    path = os.path.join(libdir, "libamdhip64.so")
     if os.path.exists(path):
         C.CDLL(path, mode=C.RTLD_GLOBAL)
+        # The library loads RCCL at first use; the copy built against that same HIP runtime is
+        # PyTorch's, so name it unless the caller has chosen one.
+        rccl = os.path.join(libdir, "librccl.so")
+        if os.path.exists(rccl):
+            os.environ.setdefault("PCL_RCCL_LIBRARY", rccl)
 
 
 def load():

@@ -161,6 +161,58 @@ class Compute:
         """One update whose pair partners are the gathered records of all ranges."""
         _lib.check(self._lib.pcl_step_pairs_gathered(self._h, C.c_void_p(int(dev_sources)), int(n_sources)))
 
+    # -- several GPUs, one process per GPU: RCCL inside the library ------------
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes that rank 0 creates and the host carries to every rank."""
+        uid = (C.c_char * _lib.UNIQUE_ID_BYTES)()
+        _lib.check(_lib.load().pcl_comm_unique_id(uid))
+        return bytes(uid)
+
+    def comm_attach(self, unique_id, rank, world):
+        """Join the communicator (ncclCommInitRank on this handle's GPU); collective."""
+        if len(unique_id) != _lib.UNIQUE_ID_BYTES:
+            raise ValueError("unique_id must be 128 bytes")
+        _lib.check(self._lib.pcl_comm_attach(self._h, C.c_char_p(bytes(unique_id)), int(rank), int(world)))
+
+    def comm_detach(self):
+        _lib.check(self._lib.pcl_comm_detach(self._h))
+
+    def comm_update_force_grid(self, force_grid, n_cells, root=0):
+        """Whole-field replace on every rank from the root's cells (others pass ``None``)."""
+        g = _as_cells(force_grid) if force_grid is not None else None
+        _lib.check(self._lib.pcl_comm_update_force_grid(self._h, _ptr(g), int(n_cells), int(root)))
+
+    def comm_patch_force_grid(self, first_cell, cells, count, root=0):
+        g = _as_cells(cells) if cells is not None else None
+        _lib.check(self._lib.pcl_comm_patch_force_grid(self._h, int(first_cell), _ptr(g), int(count), int(root)))
+
+    def comm_patch_force_grid_indexed(self, cell_indices, cells, count, root=0):
+        idx = np.ascontiguousarray(cell_indices, dtype=np.uint32).reshape(-1) if cell_indices is not None else None
+        g = _as_cells(cells) if cells is not None else None
+        _lib.check(self._lib.pcl_comm_patch_force_grid_indexed(self._h, _ptr(idx), _ptr(g), int(count), int(root)))
+
+    def comm_brush_mouse_down(self, record, root=0):
+        r = self._brush_record(record) if record is not None else None
+        _lib.check(self._lib.pcl_comm_brush_mouse_down(self._h, _ptr(r), int(root)))
+
+    def comm_brush_mouse_moved(self, record, root=0):
+        r = self._brush_record(record) if record is not None else None
+        _lib.check(self._lib.pcl_comm_brush_mouse_moved(self._h, _ptr(r), int(root)))
+
+    def comm_step(self):
+        """One update of this rank's range; all-gather first when the pair term is
+        active, all-reduce of the diagnostics when they are enabled."""
+        _lib.check(self._lib.pcl_comm_step(self._h))
+
+    def comm_diagnostics(self):
+        """Diagnostics of all ranges (identical on every rank); collective."""
+        d = _lib.Diagnostics()
+        _lib.check(self._lib.pcl_comm_diagnostics_read(self._h, C.byref(d)))
+        return {"count": int(d.count), "kinetic_energy": float(d.kinetic_energy),
+                "pos_max": np.array(d.pos_max[:], dtype=np.float32),
+                "pos_min": -np.array(d.neg_pos_min[:], dtype=np.float32)}
+
     def step_n(self, n_steps):
         """``n_steps`` updates with the result of ``n_steps`` calls of
         ``compute()``; consecutive streaming steps are fused into single

@@ -1,0 +1,32 @@
+// handle_access.hpp — what the multi-GPU layer (particles_comm.hip) needs from a
+// handle beyond the public C ABI.  Internal to the library.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+#include <string>
+
+#include "particles_hip.h"
+
+namespace pcl_internal {
+
+int fail(int code, const std::string& message);          // sets pcl_last_error(), returns code
+int make_current(const pcl_compute* h);                   // hipSetDevice(h's device)
+int device_of(const pcl_compute* h);
+hipStream_t stream_of(const pcl_compute* h);
+// Sizes the handle's field for n_cells cells (as a whole-field replace does) and returns its
+// device address, so that a collective can deliver the cells straight into it.
+int field_for_write(pcl_compute* h, size_t n_cells, void** dev_field);
+void* field_of(const pcl_compute* h);
+size_t cells_of(const pcl_compute* h);
+// Reduces the diagnostics of the latest state on the handle's stream (unless a fused per-step
+// result is current) and returns the device address of the 48-byte record.
+int diagnostics_on_device(pcl_compute* h, const void** dev_record);
+bool pair_term_active(const pcl_compute* h);              // the parameters' pair term is not provably zero
+bool step_diagnostics_enabled(const pcl_compute* h);
+// One slot for the multi-GPU layer's per-handle state; `release` runs in pcl_destroy.
+void set_comm(pcl_compute* h, void* comm, void (*release)(void*));
+void* comm_of(const pcl_compute* h);
+
+}  // namespace pcl_internal

@@ -1,0 +1,726 @@
+// particles_comm.hip — the update over several GPUs, RCCL inside the library.
+//
+// Particles shard by contiguous index range, one handle (pcl_compute) per GPU;
+// the field and the parameters are replicated.  What travels over xGMI:
+//   * the field: one ncclBroadcast straight into every handle's field buffer
+//     at construction and after a whole-field replace, the dirty range only
+//     after a patch, 20 bytes per cell for an indexed patch, and the 64-byte
+//     cursor record alone for a brush event (every replica then edits itself);
+//   * per step, only when the pair term is active: one ncclAllGather of 16
+//     bytes per particle (position and type), after which every range is
+//     updated against all records in global index order;
+//   * per step, only when step diagnostics are on: one ncclGroupStart/End pair
+//     of all-reduces over the 48-byte record (sum of count and kinetic energy
+//     in f64, max of the six f32 bounds).
+// Every collective is enqueued on the handle's own stream, so it is ordered
+// with the kernels before and after it without host synchronisation.
+//
+// Two ways to form the communicator: one process (or thread) per GPU attaches
+// its handle with a shared unique id (pcl_comm_attach: ncclCommInitRank), or
+// one process drives all GPUs of the node through a group (pcl_group_create:
+// ncclCommInitAll, every collective inside ncclGroupStart/End).  No
+// counterpart in the reference, which runs on one device
+// (src/compute.rs:221-227); the call sites a host would change are
+// src/main.rs:232-236 (construction) and src/main.rs:371-390 (per frame).
+//
+// RCCL is resolved at first use with dlopen, so the library loads (and the
+// single-GPU path runs) on machines without it; PCL_RCCL_LIBRARY names the
+// file to load when the default search (an RCCL already in the process, then
+// librccl.so.1, then librccl.so) is not wanted.
+#include "handle_access.hpp"
+
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+static_assert(PCL_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+
+namespace {
+
+using pcl_internal::fail;
+
+// ---- RCCL entry points, resolved at first use ---------------------------------
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+void load_rccl()
+{
+    Rccl& r = g_rccl;
+    const char* named = std::getenv("PCL_RCCL_LIBRARY");
+    if (named && *named) {
+        r.lib = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) { r.error = std::string("PCL_RCCL_LIBRARY=") + named + ": " + dlerror(); return; }
+    } else {
+        const char* names[] = {"librccl.so", "librccl.so.1"};
+        for (const char* n : names)   // a copy the process already holds (a framework's) wins
+            if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+        if (!r.lib) r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) { r.error = std::string("RCCL not found (librccl.so.1): ") + dlerror(); return; }
+    }
+    bool ok = true;
+    auto sym = [&](const char* name) -> void* {
+        void* p = dlsym(r.lib, name);
+        if (!p) { ok = false; r.error = std::string("RCCL lacks ") + name; }
+        return p;
+    };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) { dlclose(r.lib); r.lib = nullptr; }
+}
+
+int need_rccl()
+{
+    std::call_once(g_rccl_once, load_rccl);
+    if (!g_rccl.lib) return fail(PCL_ERR_COMM, g_rccl.error);
+    return PCL_OK;
+}
+
+#define PCL_NCCL_TRY(expr)                                                                        \
+    do {                                                                                          \
+        ncclResult_t pcl_r_ = (expr);                                                             \
+        if (pcl_r_ != ncclSuccess)                                                                \
+            return fail(PCL_ERR_COMM, std::string(#expr) + ": " + g_rccl.GetErrorString(pcl_r_)); \
+    } while (0)
+
+#define PCL_HIP_TRY(expr)                                                                   \
+    do {                                                                                    \
+        hipError_t pcl_e_ = (expr);                                                         \
+        if (pcl_e_ != hipSuccess)                                                           \
+            return fail(PCL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(pcl_e_)); \
+    } while (0)
+
+#define PCL_REQUIRE(cond, msg)                           \
+    do {                                                 \
+        if (!(cond)) return fail(PCL_ERR_INVALID, msg);  \
+    } while (0)
+
+// ---- per-handle communicator state ---------------------------------------------
+struct Comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    void* d_record = nullptr;          // 64-byte cursor record as broadcast
+    char* d_stage = nullptr;           // indexed patches: cells then indices
+    size_t stage_bytes = 0;
+    float* d_pair_send = nullptr;      // this range's 16-byte (x, y, z, type) records, padded
+    float* d_pair_recv = nullptr;      // all ranges' records
+    size_t pair_cap = 0;               // records per range in those buffers
+    unsigned long long* d_count = nullptr;   // all-reduce(max) of the local particle counts
+    unsigned long long* h_count = nullptr;   // pinned
+    pcl_diagnostics* d_global = nullptr;     // the all-reduced record
+};
+
+Comm* comm_of(pcl_compute* h) { return h ? static_cast<Comm*>(pcl_internal::comm_of(h)) : nullptr; }
+
+void release_comm(void* p)
+{
+    Comm* c = static_cast<Comm*>(p);
+    if (!c) return;
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    if (c->d_record) (void)hipFree(c->d_record);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_pair_send) (void)hipFree(c->d_pair_send);
+    if (c->d_pair_recv) (void)hipFree(c->d_pair_recv);
+    if (c->d_count) (void)hipFree(c->d_count);
+    if (c->h_count) (void)hipHostFree(c->h_count);
+    if (c->d_global) (void)hipFree(c->d_global);
+    delete c;
+}
+
+// Adopts `comm` (already initialised for h's device) as h's communicator.
+int adopt(pcl_compute* h, ncclComm_t comm, int rank, int world)
+{
+    Comm* c = new (std::nothrow) Comm();
+    if (!c) return fail(PCL_ERR_INVALID, "out of host memory");
+    c->comm = comm;
+    c->rank = rank;
+    c->world = world;
+    pcl_internal::set_comm(h, c, release_comm);   // from here on pcl_destroy releases it
+    if (int rc = pcl_internal::make_current(h)) return rc;
+    PCL_HIP_TRY(hipMalloc(&c->d_record, sizeof(pcl_brush_input)));
+    PCL_HIP_TRY(hipMalloc((void**)&c->d_count, sizeof(unsigned long long)));
+    PCL_HIP_TRY(hipHostMalloc((void**)&c->h_count, sizeof(unsigned long long), hipHostMallocDefault));
+    PCL_HIP_TRY(hipMalloc((void**)&c->d_global, sizeof(pcl_diagnostics)));
+    PCL_HIP_TRY(hipMemset(c->d_global, 0, sizeof(pcl_diagnostics)));
+    return PCL_OK;
+}
+
+// The handles one call works on: one (a rank of its own) or all of a group's.
+// Several communicators driven from one thread must be inside a group call.
+struct Span {
+    pcl_compute* const* h;
+    int n;
+};
+
+int group_begin(const Span& s) { if (s.n > 1) PCL_NCCL_TRY(g_rccl.GroupStart()); return PCL_OK; }
+int group_end(const Span& s) { if (s.n > 1) PCL_NCCL_TRY(g_rccl.GroupEnd()); return PCL_OK; }
+
+int check_span(const Span& s)
+{
+    if (int rc = need_rccl()) return rc;
+    PCL_REQUIRE(s.n >= 1, "no handle");
+    for (int i = 0; i < s.n; ++i)
+        PCL_REQUIRE(s.h[i] && comm_of(s.h[i]), "the handle has no communicator: pcl_comm_attach or pcl_group_create first");
+    return PCL_OK;
+}
+
+// Handle of the span that is rank `root` (null when another process holds it).
+pcl_compute* root_of(const Span& s, int root)
+{
+    for (int i = 0; i < s.n; ++i)
+        if (comm_of(s.h[i])->rank == root) return s.h[i];
+    return nullptr;
+}
+
+// Broadcast of `count` cells into every handle's field at `first_cell`; the root's cells come
+// from host memory (`host_cells`, only looked at where the root is in this span).
+int bcast_cells(const Span& s, const float (*host_cells)[4], size_t first_cell, size_t count, int root)
+{
+    if (count == 0) return PCL_OK;
+    if (pcl_compute* r = root_of(s, root)) {
+        PCL_REQUIRE(host_cells != nullptr, "the root rank passed no cells");
+        if (int rc = pcl_patch_force_grid(r, first_cell, host_cells, count)) return rc;   // host -> root's field (synchronises)
+    }
+    if (int rc = group_begin(s)) return rc;
+    for (int i = 0; i < s.n; ++i) {
+        pcl_compute* h = s.h[i];
+        if (int rc = pcl_internal::make_current(h)) return rc;
+        float* at = static_cast<float*>(pcl_internal::field_of(h)) + 4 * first_cell;
+        PCL_NCCL_TRY(g_rccl.Broadcast(at, at, count * 4, ncclFloat, root, comm_of(h)->comm, pcl_internal::stream_of(h)));
+    }
+    return group_end(s);
+}
+
+int update_force_grid(const Span& s, const float (*grid)[4], size_t n_cells, int root)
+{
+    if (int rc = check_span(s)) return rc;
+    PCL_REQUIRE(n_cells >= 1, "the force grid is empty");
+    PCL_REQUIRE(root >= 0 && root < comm_of(s.h[0])->world, "root rank out of range");
+    for (int i = 0; i < s.n; ++i) {
+        void* dev = nullptr;
+        if (int rc = pcl_internal::field_for_write(s.h[i], n_cells, &dev)) return rc;
+    }
+    return bcast_cells(s, grid, 0, n_cells, root);
+}
+
+int patch_force_grid(const Span& s, size_t first_cell, const float (*cells)[4], size_t count, int root)
+{
+    if (int rc = check_span(s)) return rc;
+    for (int i = 0; i < s.n; ++i)
+        if (first_cell > pcl_internal::cells_of(s.h[i]) || count > pcl_internal::cells_of(s.h[i]) - first_cell)
+            return fail(PCL_ERR_OUT_OF_RANGE, "patch_force_grid: range outside the field");
+    return bcast_cells(s, cells, first_cell, count, root);
+}
+
+int reserve_stage(pcl_compute* h, Comm* c, size_t bytes)
+{
+    if (bytes <= c->stage_bytes) return PCL_OK;
+    PCL_HIP_TRY(hipStreamSynchronize(pcl_internal::stream_of(h)));
+    if (c->d_stage) PCL_HIP_TRY(hipFree(c->d_stage));
+    c->d_stage = nullptr;
+    c->stage_bytes = 0;
+    PCL_HIP_TRY(hipMalloc((void**)&c->d_stage, bytes));
+    c->stage_bytes = bytes;
+    return PCL_OK;
+}
+
+int patch_force_grid_indexed(const Span& s, const uint32_t* idx, const float (*cells)[4], size_t count, int root)
+{
+    if (int rc = check_span(s)) return rc;
+    if (count == 0) return PCL_OK;
+    const size_t bytes = count * 20;   // 16 bytes of cell, then 4 of index
+    for (int i = 0; i < s.n; ++i) {
+        if (int rc = pcl_internal::make_current(s.h[i])) return rc;
+        if (int rc = reserve_stage(s.h[i], comm_of(s.h[i]), bytes)) return rc;
+    }
+    if (pcl_compute* r = root_of(s, root)) {
+        PCL_REQUIRE(idx != nullptr && cells != nullptr, "the root rank passed no cells");
+        for (size_t k = 0; k < count; ++k)
+            if (idx[k] >= pcl_internal::cells_of(r))
+                return fail(PCL_ERR_OUT_OF_RANGE, "patch_force_grid_indexed: cell index outside the field");
+        Comm* c = comm_of(r);
+        if (int rc = pcl_internal::make_current(r)) return rc;
+        PCL_HIP_TRY(hipMemcpyAsync(c->d_stage, cells, count * 16, hipMemcpyHostToDevice, pcl_internal::stream_of(r)));
+        PCL_HIP_TRY(hipMemcpyAsync(c->d_stage + count * 16, idx, count * 4, hipMemcpyHostToDevice, pcl_internal::stream_of(r)));
+        PCL_HIP_TRY(hipStreamSynchronize(pcl_internal::stream_of(r)));   // the caller's buffers are only valid during the call
+    }
+    if (int rc = group_begin(s)) return rc;
+    for (int i = 0; i < s.n; ++i) {
+        pcl_compute* h = s.h[i];
+        Comm* c = comm_of(h);
+        if (int rc = pcl_internal::make_current(h)) return rc;
+        PCL_NCCL_TRY(g_rccl.Broadcast(c->d_stage, c->d_stage, bytes, ncclChar, root, c->comm, pcl_internal::stream_of(h)));
+    }
+    if (int rc = group_end(s)) return rc;
+    for (int i = 0; i < s.n; ++i) {
+        Comm* c = comm_of(s.h[i]);
+        if (int rc = pcl_patch_force_grid_indexed_device(s.h[i], c->d_stage + count * 16, c->d_stage, count)) return rc;
+    }
+    return PCL_OK;
+}
+
+// The root's 64-byte cursor record on every rank's device, then the brush event there.
+int brush_event(const Span& s, const pcl_brush_input* in, int root, bool down)
+{
+    if (int rc = check_span(s)) return rc;
+    if (pcl_compute* r = root_of(s, root)) {
+        PCL_REQUIRE(in != nullptr, "the root rank passed no cursor record");
+        PCL_REQUIRE(in->mode >= PCL_EDIT_CENTERED && in->mode <= PCL_EDIT_ROTATE, "unknown edit mode");
+        PCL_REQUIRE(in->falloff >= PCL_FALLOFF_ABRUPT && in->falloff <= PCL_FALLOFF_INVERSE_DISTANCE, "unknown falloff");
+        if (int rc = pcl_internal::make_current(r)) return rc;
+        PCL_HIP_TRY(hipMemcpyAsync(comm_of(r)->d_record, in, sizeof(pcl_brush_input), hipMemcpyHostToDevice,
+                                   pcl_internal::stream_of(r)));
+        PCL_HIP_TRY(hipStreamSynchronize(pcl_internal::stream_of(r)));
+    }
+    if (int rc = group_begin(s)) return rc;
+    for (int i = 0; i < s.n; ++i) {
+        pcl_compute* h = s.h[i];
+        Comm* c = comm_of(h);
+        if (int rc = pcl_internal::make_current(h)) return rc;
+        PCL_NCCL_TRY(g_rccl.Broadcast(c->d_record, c->d_record, sizeof(pcl_brush_input), ncclChar, root, c->comm,
+                                      pcl_internal::stream_of(h)));
+    }
+    if (int rc = group_end(s)) return rc;
+    for (int i = 0; i < s.n; ++i) {
+        const int rc = down ? pcl_brush_mouse_down_device(s.h[i], comm_of(s.h[i])->d_record)
+                            : pcl_brush_mouse_moved_device(s.h[i], comm_of(s.h[i])->d_record);
+        if (rc) return rc;
+    }
+    return PCL_OK;
+}
+
+// Sum {count, kinetic energy} (f64) and max {max xyz, -min xyz} (f32) of every handle's record
+// into its d_global: one group call, two all-reduces per handle.
+int allreduce_diagnostics(const Span& s)
+{
+    std::vector<const void*> local(s.n, nullptr);
+    for (int i = 0; i < s.n; ++i)
+        if (int rc = pcl_internal::diagnostics_on_device(s.h[i], &local[i])) return rc;
+    PCL_NCCL_TRY(g_rccl.GroupStart());
+    for (int i = 0; i < s.n; ++i) {
+        pcl_compute* h = s.h[i];
+        Comm* c = comm_of(h);
+        if (int rc = pcl_internal::make_current(h)) { (void)g_rccl.GroupEnd(); return rc; }
+        const char* in = static_cast<const char*>(local[i]);
+        char* out = reinterpret_cast<char*>(c->d_global);
+        ncclResult_t r = g_rccl.AllReduce(in, out, 2, ncclDouble, ncclSum, c->comm, pcl_internal::stream_of(h));
+        if (r == ncclSuccess)
+            r = g_rccl.AllReduce(in + 16, out + 16, 6, ncclFloat, ncclMax, c->comm, pcl_internal::stream_of(h));
+        if (r != ncclSuccess) {
+            (void)g_rccl.GroupEnd();
+            return fail(PCL_ERR_COMM, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+        }
+    }
+    PCL_NCCL_TRY(g_rccl.GroupEnd());
+    return PCL_OK;
+}
+
+// Largest local particle count over all ranks (what every range is padded to in the all-gather).
+int max_local_count(const Span& s, size_t* out)
+{
+    for (int i = 0; i < s.n; ++i) {
+        pcl_compute* h = s.h[i];
+        Comm* c = comm_of(h);
+        if (int rc = pcl_internal::make_current(h)) return rc;
+        *c->h_count = (unsigned long long)pcl_num_particles(h);
+        PCL_HIP_TRY(hipMemcpyAsync(c->d_count, c->h_count, sizeof(unsigned long long), hipMemcpyHostToDevice,
+                                   pcl_internal::stream_of(h)));
+    }
+    if (int rc = group_begin(s)) return rc;
+    for (int i = 0; i < s.n; ++i) {
+        pcl_compute* h = s.h[i];
+        Comm* c = comm_of(h);
+        if (int rc = pcl_internal::make_current(h)) return rc;
+        PCL_NCCL_TRY(g_rccl.AllReduce(c->d_count, c->d_count, 1, ncclUint64, ncclMax, c->comm, pcl_internal::stream_of(h)));
+    }
+    if (int rc = group_end(s)) return rc;
+    for (int i = 0; i < s.n; ++i) {
+        pcl_compute* h = s.h[i];
+        Comm* c = comm_of(h);
+        if (int rc = pcl_internal::make_current(h)) return rc;
+        PCL_HIP_TRY(hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                   pcl_internal::stream_of(h)));
+        PCL_HIP_TRY(hipStreamSynchronize(pcl_internal::stream_of(h)));
+    }
+    *out = (size_t)*comm_of(s.h[0])->h_count;
+    return PCL_OK;
+}
+
+// One update of every range.  Pair term inert: no data-path collective at all.  Active: pack,
+// all-gather, update against all records in global index order (src/compute.wgsl:115-144 sums
+// over j = 0 .. N-1; the sharded sums then equal the one-device sums bit for bit).
+int step(const Span& s)
+{
+    if (int rc = check_span(s)) return rc;
+    const bool pairs = pcl_internal::pair_term_active(s.h[0]);
+    for (int i = 1; i < s.n; ++i)
+        PCL_REQUIRE(pcl_internal::pair_term_active(s.h[i]) == pairs, "the handles of a group hold different parameters");
+    if (!pairs) {
+        for (int i = 0; i < s.n; ++i)
+            if (int rc = pcl_step(s.h[i])) return rc;
+    } else {
+        size_t cap = 0;
+        if (int rc = max_local_count(s, &cap)) return rc;
+        if (cap == 0) {
+            for (int i = 0; i < s.n; ++i)
+                if (int rc = pcl_step(s.h[i])) return rc;
+        } else {
+            const size_t world = (size_t)comm_of(s.h[0])->world;
+            for (int i = 0; i < s.n; ++i) {
+                pcl_compute* h = s.h[i];
+                Comm* c = comm_of(h);
+                if (int rc = pcl_internal::make_current(h)) return rc;
+                if (c->pair_cap < cap) {
+                    PCL_HIP_TRY(hipStreamSynchronize(pcl_internal::stream_of(h)));
+                    if (c->d_pair_send) PCL_HIP_TRY(hipFree(c->d_pair_send));
+                    if (c->d_pair_recv) PCL_HIP_TRY(hipFree(c->d_pair_recv));
+                    c->d_pair_send = c->d_pair_recv = nullptr;
+                    c->pair_cap = 0;
+                    PCL_HIP_TRY(hipMalloc((void**)&c->d_pair_send, cap * 16));
+                    PCL_HIP_TRY(hipMalloc((void**)&c->d_pair_recv, cap * world * 16));
+                    c->pair_cap = cap;
+                }
+                if (int rc = pcl_pack_pair_sources_device(h, c->d_pair_send, cap)) return rc;
+            }
+            if (int rc = group_begin(s)) return rc;
+            for (int i = 0; i < s.n; ++i) {
+                pcl_compute* h = s.h[i];
+                Comm* c = comm_of(h);
+                if (int rc = pcl_internal::make_current(h)) return rc;
+                PCL_NCCL_TRY(g_rccl.AllGather(c->d_pair_send, c->d_pair_recv, cap * 4, ncclFloat, c->comm,
+                                              pcl_internal::stream_of(h)));
+            }
+            if (int rc = group_end(s)) return rc;
+            for (int i = 0; i < s.n; ++i)
+                if (int rc = pcl_step_pairs_gathered(s.h[i], comm_of(s.h[i])->d_pair_recv, cap * world)) return rc;
+        }
+    }
+    if (pcl_internal::step_diagnostics_enabled(s.h[0])) return allreduce_diagnostics(s);
+    return PCL_OK;
+}
+
+int diagnostics_read(const Span& s, pcl_diagnostics* out)
+{
+    if (int rc = check_span(s)) return rc;
+    PCL_REQUIRE(out != nullptr, "out is null");
+    if (int rc = allreduce_diagnostics(s)) return rc;
+    pcl_compute* h = s.h[0];
+    if (int rc = pcl_internal::make_current(h)) return rc;
+    PCL_HIP_TRY(hipMemcpyAsync(out, comm_of(h)->d_global, sizeof(pcl_diagnostics), hipMemcpyDeviceToHost,
+                               pcl_internal::stream_of(h)));
+    for (int i = 0; i < s.n; ++i)
+        if (int rc = pcl_synchronize(s.h[i])) return rc;
+    return PCL_OK;
+}
+
+}  // namespace
+
+struct pcl_group {
+    std::vector<pcl_compute*> h;
+    std::vector<size_t> first;   // first[i] .. first[i + 1]: the global indices handle i holds
+    size_t n_total = 0;
+    Span span() const { return Span{h.data(), (int)h.size()}; }
+};
+
+namespace {
+
+void split_ranges(pcl_group* g, size_t n_total)
+{
+    const size_t G = g->h.size();
+    g->n_total = n_total;
+    g->first.assign(G + 1, 0);
+    // g * N / G without overflow of the product
+    for (size_t i = 0; i <= G; ++i)
+        g->first[i] = (size_t)(((unsigned __int128)i * n_total) / G);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pcl_comm_unique_id(void* out_id)
+{
+    if (int rc = need_rccl()) return rc;
+    PCL_REQUIRE(out_id != nullptr, "pcl_comm_unique_id: out_id is null");
+    ncclUniqueId id;
+    PCL_NCCL_TRY(g_rccl.GetUniqueId(&id));
+    std::memcpy(out_id, &id, sizeof id);
+    return PCL_OK;
+}
+
+int pcl_comm_attach(pcl_compute* h, const void* unique_id, int rank, int world)
+{
+    if (int rc = need_rccl()) return rc;
+    PCL_REQUIRE(h != nullptr && unique_id != nullptr, "pcl_comm_attach: null argument");
+    PCL_REQUIRE(world >= 1 && rank >= 0 && rank < world, "pcl_comm_attach: rank outside [0, world)");
+    PCL_REQUIRE(comm_of(h) == nullptr, "pcl_comm_attach: the handle already has a communicator");
+    if (int rc = pcl_internal::make_current(h)) return rc;
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof id);
+    ncclComm_t comm = nullptr;
+    PCL_NCCL_TRY(g_rccl.CommInitRank(&comm, world, id, rank));
+    return adopt(h, comm, rank, world);
+}
+
+int pcl_comm_detach(pcl_compute* h)
+{
+    PCL_REQUIRE(h != nullptr, "null handle");
+    if (!comm_of(h)) return PCL_OK;
+    if (int rc = pcl_synchronize(h)) return rc;
+    release_comm(comm_of(h));
+    pcl_internal::set_comm(h, nullptr, nullptr);
+    return PCL_OK;
+}
+
+int pcl_comm_rank(const pcl_compute* h)
+{
+    const Comm* c = h ? static_cast<const Comm*>(pcl_internal::comm_of(h)) : nullptr;
+    return c ? c->rank : -1;
+}
+
+int pcl_comm_world(const pcl_compute* h)
+{
+    const Comm* c = h ? static_cast<const Comm*>(pcl_internal::comm_of(h)) : nullptr;
+    return c ? c->world : 0;
+}
+
+int pcl_comm_update_force_grid(pcl_compute* h, const float (*force_grid)[4], size_t n_cells, int root)
+{
+    return update_force_grid(Span{&h, 1}, force_grid, n_cells, root);
+}
+
+int pcl_comm_patch_force_grid(pcl_compute* h, size_t first_cell, const float (*cells)[4], size_t count, int root)
+{
+    return patch_force_grid(Span{&h, 1}, first_cell, cells, count, root);
+}
+
+int pcl_comm_patch_force_grid_indexed(pcl_compute* h, const uint32_t* cell_indices, const float (*cells)[4],
+                                      size_t count, int root)
+{
+    return patch_force_grid_indexed(Span{&h, 1}, cell_indices, cells, count, root);
+}
+
+int pcl_comm_brush_mouse_down(pcl_compute* h, const pcl_brush_input* in, int root)
+{
+    return brush_event(Span{&h, 1}, in, root, true);
+}
+
+int pcl_comm_brush_mouse_moved(pcl_compute* h, const pcl_brush_input* in, int root)
+{
+    return brush_event(Span{&h, 1}, in, root, false);
+}
+
+int pcl_comm_step(pcl_compute* h) { return step(Span{&h, 1}); }
+
+int pcl_comm_diagnostics_read(pcl_compute* h, pcl_diagnostics* out) { return diagnostics_read(Span{&h, 1}, out); }
+
+int pcl_comm_diagnostics_device(pcl_compute* h, const void** dev_record)
+{
+    PCL_REQUIRE(h != nullptr && dev_record != nullptr && comm_of(h) != nullptr, "pcl_comm_diagnostics_device: no communicator");
+    *dev_record = comm_of(h)->d_global;
+    return PCL_OK;
+}
+
+// ---- one process, all GPUs of the node -----------------------------------------
+
+int pcl_group_destroy(pcl_group* g)
+{
+    if (!g) return PCL_OK;
+    for (pcl_compute* h : g->h) (void)pcl_destroy(h);
+    delete g;
+    return PCL_OK;
+}
+
+int pcl_group_create(const int* devices, int n_devices, const pcl_particle* particles, size_t n,
+                     const float (*force_grid)[4], size_t n_cells, pcl_group** out)
+{
+    PCL_REQUIRE(out != nullptr, "pcl_group_create: out is null");
+    *out = nullptr;
+    if (int rc = need_rccl()) return rc;
+    PCL_REQUIRE(devices != nullptr && n_devices >= 1, "pcl_group_create: no devices");
+    PCL_REQUIRE(n == 0 || particles != nullptr, "pcl_group_create: particles is null");
+    PCL_REQUIRE(force_grid != nullptr && n_cells >= 1, "pcl_group_create: the force grid is empty");
+    pcl_group* g = new (std::nothrow) pcl_group();
+    if (!g) return fail(PCL_ERR_INVALID, "out of host memory");
+    auto cleanup = [&](int rc) { pcl_group_destroy(g); return rc; };
+    g->h.assign((size_t)n_devices, nullptr);
+    split_ranges(g, n);
+    // every handle starts with a one-cell field; the real one arrives by broadcast from rank 0
+    const float one_cell[1][4] = {{0.0f, 0.0f, 0.0f, 1.0f}};
+    for (int i = 0; i < n_devices; ++i) {
+        const size_t first = g->first[i], cnt = g->first[i + 1] - first;
+        if (int rc = pcl_create(cnt ? particles + first : nullptr, cnt, one_cell, 1, devices[i], &g->h[i])) return cleanup(rc);
+    }
+    std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
+    ncclResult_t r = g_rccl.CommInitAll(comms.data(), n_devices, devices);
+    if (r != ncclSuccess)
+        return cleanup(fail(PCL_ERR_COMM, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r)));
+    for (int i = 0; i < n_devices; ++i)
+        if (int rc = adopt(g->h[i], comms[i], i, n_devices)) {
+            for (int k = i + 1; k < n_devices; ++k) (void)g_rccl.CommDestroy(comms[k]);   // not adopted yet
+            return cleanup(rc);
+        }
+    if (int rc = update_force_grid(g->span(), force_grid, n_cells, 0)) return cleanup(rc);
+    *out = g;
+    return PCL_OK;
+}
+
+int pcl_group_size(const pcl_group* g) { return g ? (int)g->h.size() : 0; }
+
+pcl_compute* pcl_group_handle(pcl_group* g, int i)
+{
+    return (g && i >= 0 && (size_t)i < g->h.size()) ? g->h[i] : nullptr;
+}
+
+size_t pcl_group_num_particles(const pcl_group* g) { return g ? g->n_total : 0; }
+
+int pcl_group_upload_particles(pcl_group* g, const pcl_particle* particles, size_t n)
+{
+    PCL_REQUIRE(g != nullptr, "null group");
+    PCL_REQUIRE(n == 0 || particles != nullptr, "pcl_group_upload_particles: particles is null");
+    for (size_t i = 0; i < n; ++i)   // reject before any handle changes
+        PCL_REQUIRE(particles[i].ty < PCL_NUM_TYPES, "pcl_group_upload_particles: a particle's type is >= 5");
+    split_ranges(g, n);
+    for (size_t i = 0; i < g->h.size(); ++i) {
+        const size_t first = g->first[i], cnt = g->first[i + 1] - first;
+        if (int rc = pcl_upload_particles(g->h[i], cnt ? particles + first : nullptr, cnt)) return rc;
+    }
+    return PCL_OK;
+}
+
+int pcl_group_generate_particles(pcl_group* g, size_t n_total, uint64_t seed, float pos_extent, float vel_extent)
+{
+    PCL_REQUIRE(g != nullptr, "null group");
+    split_ranges(g, n_total);
+    for (size_t i = 0; i < g->h.size(); ++i)
+        if (int rc = pcl_generate_particles(g->h[i], g->first[i + 1] - g->first[i], seed, g->first[i], pos_extent, vel_extent))
+            return rc;
+    return PCL_OK;
+}
+
+int pcl_group_update_force_grid(pcl_group* g, const float (*force_grid)[4], size_t n_cells)
+{
+    PCL_REQUIRE(g != nullptr, "null group");
+    return update_force_grid(g->span(), force_grid, n_cells, 0);
+}
+
+int pcl_group_patch_force_grid(pcl_group* g, size_t first_cell, const float (*cells)[4], size_t count)
+{
+    PCL_REQUIRE(g != nullptr, "null group");
+    return patch_force_grid(g->span(), first_cell, cells, count, 0);
+}
+
+int pcl_group_patch_force_grid_indexed(pcl_group* g, const uint32_t* cell_indices, const float (*cells)[4], size_t count)
+{
+    PCL_REQUIRE(g != nullptr, "null group");
+    return patch_force_grid_indexed(g->span(), cell_indices, cells, count, 0);
+}
+
+int pcl_group_update_sim_params(pcl_group* g, const pcl_sim_params* params)
+{
+    PCL_REQUIRE(g != nullptr, "null group");
+    for (pcl_compute* h : g->h)   // replicated by value: no collective
+        if (int rc = pcl_update_sim_params(h, params)) return rc;
+    return PCL_OK;
+}
+
+int pcl_group_enable_step_diagnostics(pcl_group* g, int enable)
+{
+    PCL_REQUIRE(g != nullptr, "null group");
+    for (pcl_compute* h : g->h)
+        if (int rc = pcl_enable_step_diagnostics(h, enable)) return rc;
+    return PCL_OK;
+}
+
+int pcl_group_step(pcl_group* g)
+{
+    PCL_REQUIRE(g != nullptr, "null group");
+    return step(g->span());
+}
+
+int pcl_group_brush_mouse_down(pcl_group* g, const pcl_brush_input* in)
+{
+    PCL_REQUIRE(g != nullptr, "null group");
+    return brush_event(g->span(), in, 0, true);
+}
+
+int pcl_group_brush_mouse_moved(pcl_group* g, const pcl_brush_input* in)
+{
+    PCL_REQUIRE(g != nullptr, "null group");
+    return brush_event(g->span(), in, 0, false);
+}
+
+int pcl_group_brush_mouse_up(pcl_group* g)
+{
+    PCL_REQUIRE(g != nullptr, "null group");
+    for (pcl_compute* h : g->h)
+        if (int rc = pcl_brush_mouse_up(h)) return rc;
+    return PCL_OK;
+}
+
+int pcl_group_diagnostics_read(pcl_group* g, pcl_diagnostics* out)
+{
+    PCL_REQUIRE(g != nullptr, "null group");
+    return diagnostics_read(g->span(), out);
+}
+
+int pcl_group_read_particles(pcl_group* g, pcl_particle* out, size_t first, size_t count)
+{
+    PCL_REQUIRE(g != nullptr, "null group");
+    if (first > g->n_total || count > g->n_total - first)
+        return fail(PCL_ERR_OUT_OF_RANGE, "pcl_group_read_particles: range outside [0, n)");
+    PCL_REQUIRE(count == 0 || out != nullptr, "pcl_group_read_particles: out is null");
+    for (size_t i = 0; i < g->h.size(); ++i) {
+        const size_t lo = std::max(first, g->first[i]), hi = std::min(first + count, g->first[i + 1]);
+        if (lo < hi)
+            if (int rc = pcl_read_particles(g->h[i], out + (lo - first), lo - g->first[i], hi - lo)) return rc;
+    }
+    return PCL_OK;
+}
+
+int pcl_group_read_force_grid(pcl_group* g, int replica, float (*out)[4], size_t first_cell, size_t count)
+{
+    PCL_REQUIRE(g != nullptr && replica >= 0 && (size_t)replica < g->h.size(), "pcl_group_read_force_grid: no such replica");
+    return pcl_read_force_grid(g->h[(size_t)replica], out, first_cell, count);
+}
+
+int pcl_group_synchronize(pcl_group* g)
+{
+    PCL_REQUIRE(g != nullptr, "null group");
+    for (pcl_compute* h : g->h)
+        if (int rc = pcl_synchronize(h)) return rc;
+    return PCL_OK;
+}
+
+}  // extern "C"

@@ -15,6 +15,7 @@
 #include "brush_kernels.hpp"
 
 #include "particles_hip.h"
+#include "handle_access.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -181,6 +182,10 @@ struct pcl_compute {
 
     uint32_t grid_cap = 0;  // 0: default
     uint32_t variant = 0;
+
+    // state of the multi-GPU layer (particles_comm.hip), released in pcl_destroy
+    void* comm = nullptr;
+    void (*comm_release)(void*) = nullptr;
 
     // per-step launch timing (pcl_step_timing_*): one event pair per step
     std::vector<hipEvent_t> timing_events;
@@ -1162,6 +1167,40 @@ int brush_mouse_moved(pcl_compute* h, const pcl_brush_input* host_in, const void
 
 }  // namespace
 
+namespace pcl_internal {
+
+int fail(int code, const std::string& message) { return ::fail(code, message); }
+int make_current(const pcl_compute* h) { return bind(h); }
+int device_of(const pcl_compute* h) { return h->device; }
+hipStream_t stream_of(const pcl_compute* h) { return h->stream; }
+void* field_of(const pcl_compute* h) { return h->field; }
+size_t cells_of(const pcl_compute* h) { return h->n_cells; }
+bool pair_term_active(const pcl_compute* h) { return !pair_term_inert(h->params); }
+bool step_diagnostics_enabled(const pcl_compute* h) { return h->step_diag; }
+void set_comm(pcl_compute* h, void* comm, void (*release)(void*)) { h->comm = comm; h->comm_release = release; }
+void* comm_of(const pcl_compute* h) { return h->comm; }
+
+int field_for_write(pcl_compute* h, size_t n_cells, void** dev_field)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_REQUIRE(n_cells >= 1 && n_cells <= 0xFFFFFFFFull, "the force grid must have 1 .. 2^32 - 1 cells");
+    if (int rc = reserve_field(h, n_cells)) return rc;
+    if (n_cells != h->n_cells) h->brush_down = false;   // a selection indexes the field it was made on
+    h->n_cells = n_cells;
+    *dev_field = h->field;
+    return PCL_OK;
+}
+
+int diagnostics_on_device(pcl_compute* h, const void** dev_record)
+{
+    if (int rc = bind(h)) return rc;
+    if (int rc = ensure_diag(h)) return rc;
+    *dev_record = h->d_diag;
+    return PCL_OK;
+}
+
+}  // namespace pcl_internal
+
 extern "C" {
 
 const char* pcl_last_error(void) { return g_last_error.c_str(); }
@@ -1190,6 +1229,8 @@ int pcl_destroy(pcl_compute* h)
 {
     if (!h) return PCL_OK;
     (void)hipSetDevice(h->device);
+    if (h->comm && h->comm_release) h->comm_release(h->comm);   // while the stream still exists
+    h->comm = nullptr;
     (void)hipStreamSynchronize(h->stream);   // a null handle names the device's null stream
     if (h->own_stream && h->own_stream != h->stream) (void)hipStreamSynchronize(h->own_stream);
     free_particles(h);

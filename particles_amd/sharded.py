@@ -20,6 +20,11 @@ Under a host-memory process group (backend "gloo") the same class drives the
 GPU backend with every collective staged through the host: slower, but it
 needs no RCCL, and several ranks may then share one GPU.
 
+``collectives="native"`` moves every collective into the library
+(``pcl_comm_*`` of the C ABI: RCCL calls on the handle's own stream): the
+process group is then only used once, to carry rank 0's 128-byte unique id to
+the other ranks, and this class becomes a thin caller.
+
 The class mirrors ``Compute`` (src/compute.rs:11-228); ``compute_cls`` is the
 single-GPU backend each rank instantiates for its range.
 """
@@ -40,13 +45,17 @@ def shard_range(n_total, rank, world_size):
 
 class ShardedCompute:
     def __init__(self, particles, force_grid, *, process_group=None, device=None, compute_cls=Compute,
-                 n_total=None, seed=None, pos_extent=2.0, vel_extent=10.0, force_collectives=False):
+                 n_total=None, seed=None, pos_extent=2.0, vel_extent=10.0, force_collectives=False,
+                 collectives="torch", n_cells=None):
         """Every rank passes the full ``particles`` array and keeps its own
         range, or passes ``particles=None`` with ``n_total`` and ``seed`` to
         fill its range with the seeded synthetic scene on the device.
         ``force_grid`` is taken from rank 0 (other ranks may pass ``None``).
         ``force_collectives`` runs the broadcast / all-reduce code path even
         in a one-rank group (to exercise RCCL on a single GPU).
+        ``collectives``: "torch" (``torch.distributed`` calls) or "native"
+        (RCCL inside the library; GPU only).  ``n_cells``: the field's cell
+        count when every rank knows it, which saves the header round trip.
         """
         import torch
         import torch.distributed as dist
@@ -73,9 +82,28 @@ class ShardedCompute:
             self.n_total = int(n_total)
         self.first, self.last = shard_range(self.n_total, self.rank, self.world_size)
 
-        grid = self._replicate_field(force_grid, 0, None)
+        if collectives not in ("torch", "native"):
+            raise ValueError("collectives must be 'torch' or 'native'")
+        self._native = collectives == "native"
         local = particles[self.first:self.last] if particles is not None else np.zeros(0, dtype=PARTICLE_DTYPE)
-        if self.on_gpu and self._collectives:
+        if self._native:
+            if not self.on_gpu and dist.is_initialized() and dist.get_backend(process_group) != "gloo":
+                raise ValueError("native collectives need the GPU backend")
+            self.on_gpu = True
+            self._collectives = True
+            # the handle keeps its own stream: the library's RCCL calls are ordered on it
+            self.local = compute_cls.new(local, np.zeros((1, 4), dtype=np.float32), device=self.device)
+            uid = [Compute.comm_unique_id() if self.rank == 0 else None]
+            if dist.is_initialized():
+                dist.broadcast_object_list(uid, src=0, group=self.group)
+            self.local.comm_attach(uid[0], self.rank, self.world_size)
+            self.update_force_grid(force_grid, n_cells=n_cells)
+            grid = None
+        else:
+            grid = self._replicate_field(force_grid, 0, n_cells)
+        if self._native:
+            pass
+        elif self.on_gpu and self._collectives:
             # the replicated field is already on this device: adopt it without a host round trip
             self.local = compute_cls.new(local, np.zeros((1, 4), dtype=np.float32), device=self.device)
             self.local.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -105,18 +133,30 @@ class ShardedCompute:
         return cls(particles, force_grid, **kw)
 
     # -- field replication ------------------------------------------------
+    def _agree(self, value):
+        """Rank 0's (small, picklable) value on every rank: a host-synchronous
+        round trip, used only where the other ranks cannot know a size."""
+        box = [value if self.rank == 0 else None]
+        if self._dist.is_initialized() and self.world_size > 1:
+            self._dist.broadcast_object_list(box, src=0, group=self.group)
+        return box[0]
+
     def _replicate_field(self, cells, first_cell, count):
-        """Broadcast rank 0's cells [first_cell, first_cell+count) (count=None:
-        the whole array) and return them as a host array on every rank."""
+        """Broadcast rank 0's cells [first_cell, first_cell+count) and return
+        them on every rank.  ``count=None``: the other ranks learn the size
+        from a header that rank 0 sends first (a host-synchronous round trip);
+        when every rank passes ``count`` the payload goes out at once."""
         torch, dist = self._torch, self._dist
         if not self._collectives:
             return np.ascontiguousarray(cells, dtype=np.float32)
-        header = [None]
         if self.rank == 0:
             cells = np.ascontiguousarray(cells, dtype=np.float32)
-            header = [(int(first_cell), int(cells.shape[0]))]
-        dist.broadcast_object_list(header, src=0, group=self.group)
-        first_cell, n = header[0]
+        if count is None:
+            first_cell, n = self._agree((int(first_cell), int(cells.shape[0])) if self.rank == 0 else None)
+        else:
+            n = int(count)
+            if self.rank == 0 and cells.shape[0] != n:
+                raise ValueError("count does not match the cells rank 0 passed")
         t = torch.empty((n, 4), dtype=torch.float32, device=self._comm_device)
         if self.rank == 0:
             t.copy_(torch.from_numpy(cells))
@@ -125,38 +165,52 @@ class ShardedCompute:
         self._last_first_cell = first_cell
         return t.cpu().numpy() if not self.on_gpu else t
 
-    def update_force_grid(self, force_grid):
+    def update_force_grid(self, force_grid, n_cells=None):
         """Whole-field replace (src/compute.rs:198-204) from rank 0's array."""
-        g = self._replicate_field(force_grid, 0, None)
+        if self._native:
+            if n_cells is None:
+                n_cells = self._agree(int(np.asarray(force_grid).shape[0]) if self.rank == 0 else None)
+            self.local.comm_update_force_grid(force_grid if self.rank == 0 else None, n_cells)
+            return
+        g = self._replicate_field(force_grid, 0, n_cells)
         if self.on_gpu and self._collectives:
             self.local.update_force_grid_device(g.data_ptr(), g.shape[0])
         else:
             self.local.update_force_grid(g)
 
-    def patch_force_grid(self, first_cell, cells):
-        """Brush edit: only cells [first_cell, first_cell+len) travel."""
-        g = self._replicate_field(cells, first_cell, None)
+    def patch_force_grid(self, first_cell, cells, count=None):
+        """Brush edit: only cells [first_cell, first_cell+len) travel.  Ranks
+        other than 0 may pass ``cells=None``; when every rank passes
+        ``first_cell`` and ``count`` no header precedes the payload."""
+        if self._native:
+            if count is None:
+                first_cell, count = self._agree((int(first_cell), int(np.asarray(cells).shape[0])) if self.rank == 0 else None)
+            self.local.comm_patch_force_grid(first_cell, cells if self.rank == 0 else None, count)
+            return
+        g = self._replicate_field(cells, first_cell, count)
         first_cell = first_cell if not self._collectives else self._last_first_cell
         if self.on_gpu and self._collectives:
             self.local.patch_force_grid_device(first_cell, g.data_ptr(), g.shape[0])
         else:
             self.local.patch_force_grid(first_cell, g)
 
-    def patch_force_grid_indexed(self, cell_indices, cells):
+    def patch_force_grid_indexed(self, cell_indices, cells, count=None):
         """Brush edit of a list of cells (src/cursor.rs:84-101): rank 0's
-        ``(cell_indices, cells)`` lists are broadcast and applied everywhere."""
+        ``(cell_indices, cells)`` lists are broadcast and applied everywhere.
+        ``count`` passed by every rank saves the header round trip."""
         torch, dist = self._torch, self._dist
         if not self._collectives:
             self.local.patch_force_grid_indexed(cell_indices, cells)
             return
-        header = [None]
         if self.rank == 0:
             cell_indices = np.ascontiguousarray(cell_indices, dtype=np.uint32).reshape(-1)
             cells = np.ascontiguousarray(cells, dtype=np.float32).reshape(-1, 4)
-            header = [int(cell_indices.shape[0])]
-        dist.broadcast_object_list(header, src=0, group=self.group)
-        n = header[0]
+        n = int(count) if count is not None else self._agree(int(cell_indices.shape[0]) if self.rank == 0 else None)
         if n == 0:
+            return
+        if self._native:
+            self.local.comm_patch_force_grid_indexed(cell_indices if self.rank == 0 else None,
+                                                     cells if self.rank == 0 else None, n)
             return
         # one message: n cells of 16 bytes followed by n 4-byte indices
         buf = torch.empty(n * 5, dtype=torch.int32, device=self._comm_device)
@@ -191,6 +245,9 @@ class ShardedCompute:
     def brush_mouse_down(self, record):
         """Cursor::mouse_down (src/cursor.rs:105-116) on every replica of the
         field; ``record`` is taken from rank 0 (others may pass ``None``)."""
+        if self._native:
+            self.local.comm_brush_mouse_down(record if self.rank == 0 else None)
+            return
         r = self._replicate_brush_record(record)
         if self.on_gpu and self._collectives:
             self.local.brush_mouse_down_device(r.data_ptr())
@@ -200,6 +257,9 @@ class ShardedCompute:
     def brush_mouse_moved(self, record):
         """Cursor::mouse_moved (src/cursor.rs:79-103): every rank rewrites the
         same cells of its replica, so only the 64-byte record travels."""
+        if self._native:
+            self.local.comm_brush_mouse_moved(record if self.rank == 0 else None)
+            return
         r = self._replicate_brush_record(record)
         if self.on_gpu and self._collectives:
             self.local.brush_mouse_moved_device(r.data_ptr())
@@ -263,7 +323,12 @@ class ShardedCompute:
             self.local.step_pairs_gathered(recv_dev.data_ptr(), recv_dev.shape[0])
 
     def _advance(self, dt=None):
-        if self._pair_active and self._collectives and self.n_total > 0:
+        if self._native:
+            if dt is not None:      # step(dt) = set delta_t, then one update
+                self._params.delta_t = dt
+                self.local.update_sim_params(self._params)
+            self.local.comm_step()  # all-gather (pair term) and diagnostics all-reduce happen inside
+        elif self._pair_active and self._collectives and self.n_total > 0:
             if dt is not None:      # step(dt) = set delta_t, then one update
                 self._params.delta_t = dt
                 self.local.update_sim_params(self._params)
@@ -287,6 +352,10 @@ class ShardedCompute:
     def compute_n(self, n_steps):
         """``n_steps`` updates of the local range (fused launches where the
         path allows); step diagnostics describe the final state."""
+        if self._native and self._pair_active:
+            for _ in range(int(n_steps)):
+                self.local.comm_step()
+            return
         if self._pair_active and self._collectives and self.n_total > 0:
             for _ in range(int(n_steps)):
                 self._pair_step()
@@ -324,6 +393,8 @@ class ShardedCompute:
 
     def _start_diag_allreduce(self):
         torch, dist = self._torch, self._dist
+        if self._native:
+            return      # pcl_comm_step starts it on the handle's stream; diagnostics() reads it
         self._fill_diag_buf()
         if self._collectives:
             sums = self._diag_buf[:16].view(torch.float64)     # count, kinetic energy
@@ -341,6 +412,8 @@ class ShardedCompute:
 
     def diagnostics(self):
         """Global diagnostics of the latest state (identical on every rank)."""
+        if self._native:
+            return self.local.comm_diagnostics()
         if not self._diag_enabled:
             self._start_diag_allreduce()
         self.wait()

@@ -174,6 +174,62 @@ def test_sharded_device_brush_over_rccl(oracle, one_rank_rccl):
     assert_particles_bit_equal(got_p, want_p, "sharded device brush over RCCL")
 
 
+def test_sharded_native_collectives(oracle, one_rank_rccl):
+    """ShardedCompute with the collectives inside the library (pcl_comm_*): the
+    process group only carries the unique id; brush, patches with and without a
+    size header, diagnostics and the pair term's all-gather all run as RCCL
+    calls on the handle's own stream."""
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    sp.force_grid_dimensions = (64, 64, 1)
+    g = scene_swirl_field(64, 64, 1, 10.0, seed=6)
+    p = oracle.synth_particles(30001, seed=12, pos_extent=20.0, vel_extent=10.0)
+    em = pa.EditMode(mode="shift", falloff="linear", falloff_dist=2.0, strength=0.5)
+    m = oracle.edit_mode("shift", True, "linear", 2.0, 0.5)
+    sc = pa.ShardedCompute.new(p.view(pa.PARTICLE_DTYPE), g, collectives="native", n_cells=64 * 64)
+    try:
+        assert sc.local._lib.pcl_comm_world(sc.local._h) == 1
+        sc.update_sim_params(sp)
+        sc.enable_step_diagnostics(True)
+        brush = pa.DeviceBrush(sc, em)
+        brush.mouse_down((0.5, -0.5, 0.0))
+        idx, vec = oracle.brush_mouse_down(sp, g, (0.5, -0.5, 0.0), 2.0)
+        brush.mouse_moved((1.0, 0.0, 0.0))
+        want_g = oracle.brush_mouse_moved(sp, g, m, idx, vec, (0.5, -0.5, 0.0), (1.0, 0.0, 0.0))
+        patch = np.full((50, 4), 0.75, dtype=np.float32)
+        sc.patch_force_grid(2000, patch, count=50)           # every rank knows the size: no header
+        sc.patch_force_grid(3000, patch[:7])                 # size carried by a header
+        sc.patch_force_grid_indexed(np.array([5, 4095], dtype=np.uint32), patch[:2])
+        want_g[2000:2050] = 0.75
+        want_g[3000:3007] = 0.75
+        want_g[[5, 4095]] = 0.75
+        for _ in range(3):
+            sc.compute()
+        sc.compute_n(4)
+        want = oracle.run(sp, p, want_g, 7, mode=oracle.MODE_SKIP_INERT)
+        assert sc.read_force_grid().tobytes() == want_g.tobytes()
+        assert_particles_bit_equal(sc.gather_particles(), want, "native collectives, streaming")
+        d, wd = sc.diagnostics(), oracle.diagnostics(sp, want)
+        assert d["count"] == 30001 and abs(d["kinetic_energy"] - wd["kinetic_energy"]) <= 1e-12 * wd["kinetic_energy"]
+        assert np.array_equal(d["pos_max"], wd["pos_max"]) and np.array_equal(d["pos_min"], wd["pos_min"])
+        # pair term: the all-gather inside pcl_comm_step
+        sp2, p2, g2 = pair_scene(oracle, 1501)
+        sc.upload_particles(p2.view(pa.PARTICLE_DTYPE))
+        sc.update_force_grid(g2)
+        sc.update_sim_params(sp2)
+        sc.local.set_pair_mode(pa.PAIRS_ALL)
+        sc.compute()
+        sc.step(1.0 / 120.0)
+        assert sc.local.last_step_kernel == pa.KERNEL_PAIRS
+        want = oracle.run(sp2, p2, g2, 1)
+        sp2.delta_t = np.float32(1.0 / 120.0)
+        want = oracle.run(sp2, want, g2, 1)
+        assert_particles_bit_equal(sc.gather_particles(), want, "native collectives, pair steps")
+    finally:
+        sc.close()
+
+
 @pytest.mark.parametrize("tile_order", [False, True])
 def test_instance_stream_pack_on_the_device(oracle, tile_order):
     """pcl_pack_particles_device[_unordered]: the 48-byte records the renderer
