@@ -32,8 +32,14 @@ $(COMM_OBJ): $(COMM_SRC) $(HDRS)
 	mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $(COMM_SRC)
 
-$(LIB): $(MAIN_OBJ) $(SORT_OBJ) $(COMM_OBJ)
-	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $(MAIN_OBJ) $(SORT_OBJ) $(COMM_OBJ) -ldl
+# host-only authoring helpers (force curves through sample points, initial fields)
+AUTH_OBJ  := build/authoring.o
+$(AUTH_OBJ): particles_amd/csrc/authoring.cpp include/particles_hip.h
+	mkdir -p build
+	g++ -O2 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -Wall -Wextra -Iinclude -c -o $@ $<
+
+$(LIB): $(MAIN_OBJ) $(SORT_OBJ) $(COMM_OBJ) $(AUTH_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $(MAIN_OBJ) $(SORT_OBJ) $(COMM_OBJ) $(AUTH_OBJ) -ldl
 
 oracle:
 	$(MAKE) -C oracle

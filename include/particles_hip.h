@@ -90,7 +90,8 @@ enum {
                                   memory had an unknown mode or falloff).  Returned once, by the next call that
                                   synchronises the stream (pcl_synchronize, pcl_read_*, pcl_diagnostics_read,
                                   pcl_debug_cell_indices, pcl_brush_selection); pcl_last_error() says which */
-    PCL_ERR_COMM         = -6  /* RCCL could not be loaded, or one of its calls failed                           */
+    PCL_ERR_COMM         = -6, /* RCCL could not be loaded, or one of its calls failed                           */
+    PCL_ERR_SINGULAR     = -7  /* pcl_poly7_from_points: no polynomial (where the reference returns None)          */
 };
 
 /* Which kernel family pcl_step picked (see pcl_last_step_kernel). */
@@ -437,6 +438,33 @@ int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks,
  *   0x40000  tests only: the next refresh of the particle order scatters with other keys than its
  *            histogram counted, which the kernel reports as PCL_ERR_DEVICE (the state is then unusable) */
 int pcl_set_tuning(pcl_compute* h, uint32_t grid_blocks, uint32_t variant);
+
+/* ---- authoring helpers (host only, no device needed) -----------------------
+ * What the reference's GUI uses to build the update's inputs; fp32 operation
+ * for operation in the reference's order. */
+
+/* Poly7::from_points, src/poly7.rs:37-58: the polynomial through eight (x, y)
+ * points, by inverting the 8x8 Vandermonde matrix with the reference's
+ * Gauss-Jordan elimination without pivot search (src/poly7.rs:120-147) and
+ * multiplying by the y values.  x^j is f32::powi (square-and-multiply, as
+ * compiler-rt's __powisf2).  PCL_ERR_SINGULAR where the reference returns None
+ * (a non-finite entry in the inverse, e.g. a repeated x). */
+int pcl_poly7_from_points(const float (*points)[2], pcl_poly7* out);
+/* Poly7::eval, src/poly7.rs:60-68 (the GUI's plotting order, ascending powers
+ * with a running product; the shader evaluates in another order). */
+float pcl_poly7_eval(const pcl_poly7* p, float x);
+/* Grid::new_centered + get_force_vectors, src/grid.rs:68-103: cell (ix,iy,iz)
+ * holds (nx,ny,nz)*0.5 - (ix,iy,iz), w = 1; x slowest, z fastest. */
+void pcl_grid_centered(size_t nx, size_t ny, size_t nz, float (*out)[4]);
+/* Grid::new_uniform + get_force_vectors, src/grid.rs:49-64,97-103. */
+void pcl_grid_uniform(size_t nx, size_t ny, size_t nz, const float value[3], float (*out)[4]);
+/* Grid::get_positions, src/grid.rs:119-138: cell-centre positions for bounds
+ * (pos, dir). */
+void pcl_grid_positions(size_t nx, size_t ny, size_t nz, const float bounds_pos[3], const float bounds_dir[3],
+                        float (*out)[4]);
+/* SimParams::new_force_grid_centered (centered != 0) / new_force_grid_zero,
+ * src/sim_params.rs:33-60, as upload-ready cells for the block's dimensions. */
+int pcl_sim_params_force_grid(const pcl_sim_params* params, int centered, float (*out)[4], size_t capacity_cells);
 
 /* ======================================================================
  * Several GPUs of one node (RCCL over xGMI inside the library).

@@ -65,6 +65,11 @@ def load():
     lib.orc_lattice_particles.argtypes = [vp, f, f, f, sz, sz, sz]
     lib.orc_grid_centered.argtypes = [vp, sz, sz, sz]
     lib.orc_grid_positions.argtypes = [vp, sz, sz, sz, f]
+    lib.orc_grid_uniform.argtypes = [vp, sz, sz, sz, f, f, f]
+    lib.orc_poly7_from_points.restype = i
+    lib.orc_poly7_from_points.argtypes = [vp, vp]
+    lib.orc_poly7_eval_host.restype = f
+    lib.orc_poly7_eval_host.argtypes = [vp, f]
     lib.orc_synth_uniform.restype = f
     lib.orc_synth_uniform.argtypes = [u64, u64, u32]
     lib.orc_synth_particles.argtypes = [vp, sz, u64, u64, f, f]
@@ -185,6 +190,24 @@ def grid_centered(nx, ny, nz):
     out = np.zeros((nx * ny * nz, 4), dtype=np.float32)
     load().orc_grid_centered(_p(out), nx, ny, nz)
     return out
+
+
+def grid_uniform(nx, ny, nz, value=(0.0, 0.0, 0.0)):
+    out = np.zeros((nx * ny * nz, 4), dtype=np.float32)
+    load().orc_grid_uniform(_p(out), nx, ny, nz, float(value[0]), float(value[1]), float(value[2]))
+    return out
+
+
+def poly7_from_points(points):
+    """Coefficients (float32[8]) of the polynomial through 8 (x, y) points, or None."""
+    pts = np.ascontiguousarray(points, dtype=np.float32).reshape(8, 2)
+    out = np.zeros(8, dtype=np.float32)
+    return out if load().orc_poly7_from_points(_p(pts), _p(out)) else None
+
+
+def poly7_eval_host(coeffs, x):
+    c = np.ascontiguousarray(coeffs, dtype=np.float32).reshape(8)
+    return np.float32(load().orc_poly7_eval_host(_p(c), float(x)))
 
 
 def grid_positions(nx, ny, nz, radius):

@@ -403,6 +403,80 @@ void orc_grid_centered(float (*out)[4], size_t nx, size_t ny, size_t nz)
             }
 }
 
+/* Grid::new_uniform + get_force_vectors: src/grid.rs:49-64,97-103. */
+void orc_grid_uniform(float (*out)[4], size_t nx, size_t ny, size_t nz, float vx, float vy, float vz)
+{
+    for (size_t k = 0; k < nx * ny * nz; ++k) {
+        out[k][0] = vx; out[k][1] = vy; out[k][2] = vz; out[k][3] = 1.0f;
+    }
+}
+
+/* f32::powi for a non-negative exponent.  Rust lowers it to llvm.powi, which
+ * is compiler-rt's __powisf2 (or, for a constant exponent, LLVM's in-line
+ * expansion of the same square-and-multiply sequence, low bit first). */
+static float orc_powi(float a, int b)
+{
+    float r = 1.0f;
+    while (1) {
+        if (b & 1) r = r * a;
+        b = b / 2;
+        if (b == 0) break;
+        a = a * a;
+    }
+    return r;
+}
+
+/* Poly7::from_points: src/poly7.rs:37-58, with inverse() of src/poly7.rs:120-147
+ * (elimination without pivot search; every row operation applied to the matrix
+ * and to the identity beside it, element by element, left to right) and
+ * multiply_vector of src/poly7.rs:110-118.  Returns 0 where the reference
+ * returns None (a non-finite entry in the inverse), 1 otherwise. */
+int orc_poly7_from_points(const float (*pts)[2], float coeffs[8])
+{
+    float m[8][8], res[8][8];
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) {
+            m[i][j] = orc_powi(pts[i][0], j);
+            res[i][j] = (i == j) ? 1.0f : 0.0f;
+        }
+    for (int i = 0; i < 8; ++i) {
+        for (int j = i + 1; j < 8; ++j) {
+            const float pivot = -m[j][i] / m[i][i];
+            for (int k = 0; k < 8; ++k) m[j][k] = m[j][k] + pivot * m[i][k];
+            for (int k = 0; k < 8; ++k) res[j][k] = res[j][k] + pivot * res[i][k];
+        }
+        const float div = m[i][i];
+        for (int k = 0; k < 8; ++k) m[i][k] = m[i][k] / div;
+        for (int k = 0; k < 8; ++k) res[i][k] = res[i][k] / div;
+    }
+    for (int i = 7; i >= 0; --i)
+        for (int j = i - 1; j >= 0; --j) {
+            const float pivot = -m[j][i] / m[i][i];
+            for (int k = 0; k < 8; ++k) m[j][k] = m[j][k] + pivot * m[i][k];
+            for (int k = 0; k < 8; ++k) res[j][k] = res[j][k] + pivot * res[i][k];
+        }
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j)
+            if (!isfinite(res[i][j])) return 0;
+    for (int row = 0; row < 8; ++row) {
+        float acc = 0.0f;
+        for (int i = 0; i < 8; ++i) acc = acc + res[row][i] * pts[i][1];
+        coeffs[row] = acc;
+    }
+    return 1;
+}
+
+/* Poly7::eval: src/poly7.rs:60-68 (ascending powers, running product). */
+float orc_poly7_eval_host(const float coeffs[8], float x)
+{
+    float res = 0.0f, x_to_the_i = 1.0f;
+    for (int i = 0; i < 8; ++i) {
+        res = res + x_to_the_i * coeffs[i];
+        x_to_the_i = x_to_the_i * x;
+    }
+    return res;
+}
+
 /* Grid::get_positions: src/grid.rs:119-138 with bounds pos = -r, dir = 2r
  * (src/sim_params.rs:33-45). */
 void orc_grid_positions(float (*out)[4], size_t nx, size_t ny, size_t nz, float radius)

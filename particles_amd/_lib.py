@@ -16,6 +16,7 @@ PCL_ERR_NO_DEVICE = -3
 PCL_ERR_OUT_OF_RANGE = -4
 PCL_ERR_DEVICE = -5
 PCL_ERR_COMM = -6
+PCL_ERR_SINGULAR = -7
 UNIQUE_ID_BYTES = 128
 
 KERNEL_NONE, KERNEL_STREAM, KERNEL_PAIRS = 0, 1, 2
@@ -103,6 +104,13 @@ SIGNATURES = {
     "pcl_reorder_now": (_i, [_vp]),
     "pcl_reorder_count": (_u64, [_vp]),
     "pcl_set_tuning": (_i, [_vp, _u32, _u32]),
+    # authoring helpers (host only)
+    "pcl_poly7_from_points": (_i, [_vp, _vp]),
+    "pcl_poly7_eval": (_f, [_vp, _f]),
+    "pcl_grid_centered": (None, [_sz, _sz, _sz, _vp]),
+    "pcl_grid_uniform": (None, [_sz, _sz, _sz, _vp, _vp]),
+    "pcl_grid_positions": (None, [_sz, _sz, _sz, _vp, _vp, _vp]),
+    "pcl_sim_params_force_grid": (_i, [_vp, _i, _vp, _sz]),
     # several GPUs: RCCL inside the library
     "pcl_comm_unique_id": (_i, [_vp]),
     "pcl_comm_attach": (_i, [_vp, _vp, _i, _i]),

@@ -45,43 +45,20 @@ class Poly7:
 
     @classmethod
     def from_points(cls, points):
-        """Interpolating polynomial through 8 (x, y) points: src/poly7.rs:37-58.
-
-        Builds the 8x8 Vandermonde matrix in fp32, inverts it with the
-        reference's pivot-free Gauss-Jordan elimination (src/poly7.rs:120-147)
-        and multiplies by the y values.  Returns ``None`` when the inverse has
-        a non-finite entry (repeated x), as the reference does.
-        """
-        pts = np.asarray(points, dtype=np.float32)
+        """Interpolating polynomial through 8 (x, y) points: src/poly7.rs:37-58
+        (``pcl_poly7_from_points`` of the C ABI: the 8x8 Vandermonde matrix in
+        fp32 with ``powi`` powers, the reference's Gauss-Jordan elimination
+        without pivot search, src/poly7.rs:120-147, then the product with the y
+        values).  Returns ``None`` where the reference does (a non-finite entry
+        in the inverse, e.g. a repeated x)."""
+        import ctypes as C
+        from . import _lib
+        pts = np.ascontiguousarray(points, dtype=np.float32)
         if pts.shape != (8, 2):
             raise ValueError("from_points takes 8 (x, y) pairs")
-        f32 = np.float32
-        n = 8
-        m = np.empty((n, n), dtype=np.float32)
-        for i in range(n):
-            for j in range(n):
-                m[i, j] = f32(pts[i, 0]) ** j if j else f32(1.0)  # powi
-        res = np.eye(n, dtype=np.float32)
-        with np.errstate(all="ignore"):
-            for i in range(n):
-                for j in range(i + 1, n):
-                    pivot = f32(-m[j, i] / m[i, i])
-                    m[j, :] = m[j, :] + pivot * m[i, :]
-                    res[j, :] = res[j, :] + pivot * res[i, :]
-                div = f32(m[i, i])
-                m[i, :] = m[i, :] / div
-                res[i, :] = res[i, :] / div
-            for i in range(n - 1, -1, -1):
-                for j in range(i - 1, -1, -1):
-                    pivot = f32(-m[j, i] / m[i, i])
-                    m[j, :] = m[j, :] + pivot * m[i, :]
-                    res[j, :] = res[j, :] + pivot * res[i, :]
-            if not np.all(np.isfinite(res)):
-                return None
-            coeffs = np.zeros(n, dtype=np.float32)
-            for r in range(n):
-                acc = f32(0.0)
-                for i in range(n):
-                    acc = f32(acc + res[r, i] * pts[i, 1])
-                coeffs[r] = acc
-        return cls(coeffs)
+        out = np.zeros(8, dtype=np.float32)
+        rc = _lib.load().pcl_poly7_from_points(pts.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        if rc == _lib.PCL_ERR_SINGULAR:
+            return None
+        _lib.check(rc)
+        return cls(out)
