@@ -18,6 +18,30 @@ struct PclCompute {
     _private: [u8; 0],
 }
 
+#[repr(C)]
+struct PclGroup {
+    _private: [u8; 0],
+}
+
+/// `pcl_diagnostics`: count, kinetic energy (f64 sums), bounds of the positions.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct Diagnostics {
+    pub count: f64,
+    pub kinetic_energy: f64,
+    pub pos_max: [f32; 3],
+    /// -(min x), -(min y), -(min z): reducible with max like `pos_max`
+    pub neg_pos_min: [f32; 3],
+    pub pad: [f32; 2],
+}
+
+/// `Poly7` of the reference (src/poly7.rs:6-10): `coeffs[i]` multiplies x^i.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct Poly7 {
+    pub coeffs: [f32; 8],
+}
+
 extern "C" {
     fn pcl_last_error() -> *const c_char;
     fn pcl_create(particles: *const c_void, n: usize, force_grid: *const [f32; 4], n_cells: usize,
@@ -39,6 +63,51 @@ extern "C" {
     fn pcl_brush_mouse_moved(h: *mut PclCompute, input: *const BrushInput) -> c_int;
     fn pcl_brush_mouse_up(h: *mut PclCompute) -> c_int;
     fn pcl_read_force_grid(h: *mut PclCompute, out: *mut [f32; 4], first_cell: usize, count: usize) -> c_int;
+    fn pcl_patch_force_grid_indexed(h: *mut PclCompute, cell_indices: *const u32, cells: *const [f32; 4], count: usize) -> c_int;
+    fn pcl_enable_step_diagnostics(h: *mut PclCompute, enable: c_int) -> c_int;
+    fn pcl_diagnostics_read(h: *mut PclCompute, out: *mut Diagnostics) -> c_int;
+    fn pcl_device_count() -> c_int;
+    fn pcl_poly7_from_points(points: *const [f32; 2], out: *mut Poly7) -> c_int;
+    fn pcl_poly7_eval(p: *const Poly7, x: f32) -> f32;
+    // several GPUs, one process: RCCL inside the library
+    fn pcl_group_create(devices: *const c_int, n_devices: c_int, particles: *const c_void, n: usize,
+                        force_grid: *const [f32; 4], n_cells: usize, out: *mut *mut PclGroup) -> c_int;
+    fn pcl_group_destroy(g: *mut PclGroup) -> c_int;
+    fn pcl_group_size(g: *const PclGroup) -> c_int;
+    fn pcl_group_upload_particles(g: *mut PclGroup, particles: *const c_void, n: usize) -> c_int;
+    fn pcl_group_update_force_grid(g: *mut PclGroup, force_grid: *const [f32; 4], n_cells: usize) -> c_int;
+    fn pcl_group_patch_force_grid(g: *mut PclGroup, first_cell: usize, cells: *const [f32; 4], count: usize) -> c_int;
+    fn pcl_group_patch_force_grid_indexed(g: *mut PclGroup, cell_indices: *const u32, cells: *const [f32; 4], count: usize) -> c_int;
+    fn pcl_group_update_sim_params(g: *mut PclGroup, params: *const c_void) -> c_int;
+    fn pcl_group_enable_step_diagnostics(g: *mut PclGroup, enable: c_int) -> c_int;
+    fn pcl_group_step(g: *mut PclGroup) -> c_int;
+    fn pcl_group_brush_mouse_down(g: *mut PclGroup, input: *const BrushInput) -> c_int;
+    fn pcl_group_brush_mouse_moved(g: *mut PclGroup, input: *const BrushInput) -> c_int;
+    fn pcl_group_brush_mouse_up(g: *mut PclGroup) -> c_int;
+    fn pcl_group_diagnostics_read(g: *mut PclGroup, out: *mut Diagnostics) -> c_int;
+    fn pcl_group_read_particles(g: *mut PclGroup, out: *mut c_void, first: usize, count: usize) -> c_int;
+    fn pcl_group_synchronize(g: *mut PclGroup) -> c_int;
+}
+
+impl Poly7 {
+    /// `Poly7::from_points` (src/poly7.rs:37-58); `None` where the reference returns `None`.
+    pub fn from_points(points: &[[f32; 2]; 8]) -> Option<Poly7> {
+        let mut out = Poly7::default();
+        match unsafe { pcl_poly7_from_points(points.as_ptr(), &mut out) } {
+            0 => Some(out),
+            _ => None,
+        }
+    }
+
+    /// `Poly7::eval` (src/poly7.rs:60-68).
+    pub fn eval(&self, x: f32) -> f32 {
+        unsafe { pcl_poly7_eval(self, x) }
+    }
+}
+
+/// Number of HIP devices the library sees.
+pub fn device_count() -> usize {
+    unsafe { pcl_device_count() }.max(0) as usize
 }
 
 /// What `Cursor` and `EditMode` hold per mouse event (src/cursor.rs:5-17,144-151),
@@ -88,15 +157,26 @@ pub struct Compute {
 }
 
 impl Compute {
-    /// `Compute::new(device, particles, force_grid)`: src/compute.rs:25.
+    /// `Compute::new(device, particles, force_grid)`: src/compute.rs:25, on HIP device 0.
     pub fn new<P: bytemuck::NoUninit>(particles: &[P], force_grid: &[[f32; 4]]) -> Self {
+        Self::new_on_device(0, particles, force_grid)
+    }
+
+    /// The same on the HIP device with ordinal `device` (the wgpu `&Device` argument's stand-in).
+    pub fn new_on_device<P: bytemuck::NoUninit>(device: i32, particles: &[P], force_grid: &[[f32; 4]]) -> Self {
         assert_eq!(std::mem::size_of::<P>(), 48, "Particle must be the reference's 48-byte record");
         let mut handle = std::ptr::null_mut();
         check(unsafe {
             pcl_create(particles.as_ptr() as *const c_void, particles.len(), force_grid.as_ptr(),
-                       force_grid.len(), 0, &mut handle)
+                       force_grid.len(), device as c_int, &mut handle)
         });
         Compute { handle, num_particles: particles.len() }
+    }
+
+    /// Particles sharded by index range over `devices` (all visible ones when empty), the field
+    /// replicated by RCCL broadcast inside the library: same methods, every GPU of the node.
+    pub fn new_sharded<P: bytemuck::NoUninit>(devices: &[i32], particles: &[P], force_grid: &[[f32; 4]]) -> ShardedCompute {
+        ShardedCompute::new(devices, particles, force_grid)
     }
 
     /// src/compute.rs:182-196.
@@ -116,10 +196,28 @@ impl Compute {
         check(unsafe { pcl_patch_force_grid(self.handle, first_cell, cells.as_ptr(), cells.len()) });
     }
 
+    /// Brush edits as a list of cells (the write loop of src/cursor.rs:84-101).
+    pub fn patch_force_grid_indexed(&mut self, cell_indices: &[u32], cells: &[[f32; 4]]) {
+        assert_eq!(cell_indices.len(), cells.len());
+        check(unsafe { pcl_patch_force_grid_indexed(self.handle, cell_indices.as_ptr(), cells.as_ptr(), cells.len()) });
+    }
+
     /// src/compute.rs:206-219.
     pub fn update_sim_params<S: bytemuck::NoUninit>(&mut self, sim_params: &S) {
         assert_eq!(std::mem::size_of::<S>(), 912, "SimParams must be the reference's 912-byte block");
         check(unsafe { pcl_update_sim_params(self.handle, sim_params as *const S as *const c_void) });
+    }
+
+    /// Fuse count / kinetic energy / bounds into every step (no extra pass over the particles).
+    pub fn enable_step_diagnostics(&mut self, enable: bool) {
+        check(unsafe { pcl_enable_step_diagnostics(self.handle, enable as c_int) });
+    }
+
+    /// Count, kinetic energy and bounds of the latest state (synchronises).
+    pub fn diagnostics(&mut self) -> Diagnostics {
+        let mut d = Diagnostics::default();
+        check(unsafe { pcl_diagnostics_read(self.handle, &mut d) });
+        d
     }
 
     /// src/compute.rs:221-227: one update, asynchronous on the HIP stream.
@@ -187,5 +285,103 @@ impl Compute {
 impl Drop for Compute {
     fn drop(&mut self) {
         unsafe { pcl_destroy(self.handle) };
+    }
+}
+
+/// `Compute` over several GPUs of one node driven by this process (`pcl_group_*`): particles
+/// shard by contiguous index range, the field replicas are kept equal by RCCL broadcasts, and
+/// with step diagnostics on every step all-reduces the 48-byte record.
+pub struct ShardedCompute {
+    group: *mut PclGroup,
+    pub num_particles: usize,
+}
+
+impl ShardedCompute {
+    pub fn new<P: bytemuck::NoUninit>(devices: &[i32], particles: &[P], force_grid: &[[f32; 4]]) -> Self {
+        assert_eq!(std::mem::size_of::<P>(), 48, "Particle must be the reference's 48-byte record");
+        let all: Vec<c_int> = if devices.is_empty() {
+            (0..device_count().max(1) as c_int).collect()
+        } else {
+            devices.iter().map(|&d| d as c_int).collect()
+        };
+        let mut group = std::ptr::null_mut();
+        check(unsafe {
+            pcl_group_create(all.as_ptr(), all.len() as c_int, particles.as_ptr() as *const c_void, particles.len(),
+                             force_grid.as_ptr(), force_grid.len(), &mut group)
+        });
+        ShardedCompute { group, num_particles: particles.len() }
+    }
+
+    pub fn num_gpus(&self) -> usize {
+        unsafe { pcl_group_size(self.group) }.max(0) as usize
+    }
+
+    pub fn upload_particles<P: bytemuck::NoUninit>(&mut self, particles: &[P]) {
+        assert_eq!(std::mem::size_of::<P>(), 48);
+        self.num_particles = particles.len();
+        check(unsafe { pcl_group_upload_particles(self.group, particles.as_ptr() as *const c_void, particles.len()) });
+    }
+
+    pub fn update_force_grid(&mut self, force_grid: &[[f32; 4]]) {
+        check(unsafe { pcl_group_update_force_grid(self.group, force_grid.as_ptr(), force_grid.len()) });
+    }
+
+    pub fn patch_force_grid(&mut self, first_cell: usize, cells: &[[f32; 4]]) {
+        check(unsafe { pcl_group_patch_force_grid(self.group, first_cell, cells.as_ptr(), cells.len()) });
+    }
+
+    pub fn patch_force_grid_indexed(&mut self, cell_indices: &[u32], cells: &[[f32; 4]]) {
+        assert_eq!(cell_indices.len(), cells.len());
+        check(unsafe { pcl_group_patch_force_grid_indexed(self.group, cell_indices.as_ptr(), cells.as_ptr(), cells.len()) });
+    }
+
+    pub fn update_sim_params<S: bytemuck::NoUninit>(&mut self, sim_params: &S) {
+        assert_eq!(std::mem::size_of::<S>(), 912);
+        check(unsafe { pcl_group_update_sim_params(self.group, sim_params as *const S as *const c_void) });
+    }
+
+    pub fn enable_step_diagnostics(&mut self, enable: bool) {
+        check(unsafe { pcl_group_enable_step_diagnostics(self.group, enable as c_int) });
+    }
+
+    /// One update of every range (src/compute.rs:221-227 on every GPU).
+    pub fn compute(&mut self) {
+        check(unsafe { pcl_group_step(self.group) });
+    }
+
+    pub fn brush_mouse_down(&mut self, input: &BrushInput) {
+        check(unsafe { pcl_group_brush_mouse_down(self.group, input) });
+    }
+
+    pub fn brush_mouse_moved(&mut self, input: &BrushInput) {
+        check(unsafe { pcl_group_brush_mouse_moved(self.group, input) });
+    }
+
+    pub fn brush_mouse_up(&mut self) {
+        check(unsafe { pcl_group_brush_mouse_up(self.group) });
+    }
+
+    /// Diagnostics of the whole set (all-reduced over the GPUs).
+    pub fn diagnostics(&mut self) -> Diagnostics {
+        let mut d = Diagnostics::default();
+        check(unsafe { pcl_group_diagnostics_read(self.group, &mut d) });
+        d
+    }
+
+    pub fn read_particles<P: bytemuck::Pod>(&mut self, first: usize, count: usize) -> Vec<P> {
+        assert_eq!(std::mem::size_of::<P>(), 48);
+        let mut out = vec![P::zeroed(); count];
+        check(unsafe { pcl_group_read_particles(self.group, out.as_mut_ptr() as *mut c_void, first, count) });
+        out
+    }
+
+    pub fn synchronize(&mut self) {
+        check(unsafe { pcl_group_synchronize(self.group) });
+    }
+}
+
+impl Drop for ShardedCompute {
+    fn drop(&mut self) {
+        unsafe { pcl_group_destroy(self.group) };
     }
 }
