@@ -58,11 +58,11 @@ def swirl_field(nx, ny, nz, radius, seed):
     return out
 
 
-def make_params(pa, dims):
+def make_params(pa, dims, masses=MASSES):
     sp = pa.SimParams()
     sp.delta_t = np.float32(DT)
     sp.force_grid_dimensions = dims
-    sp.masses = MASSES
+    sp.masses = tuple(masses)
     sp.bounding_volume_radius = RADIUS
     sp.max_velocity = 100.0
     return sp
@@ -157,6 +157,8 @@ def main():
                     help="initial velocities are vel_extent*(u-0.5) per axis (10: about 4 field cells per step)")
     ap.add_argument("--diagnostics", choices=("on", "off"), default="off",
                     help="fuse count/kinetic-energy/bounds into the step and all-reduce them per step")
+    ap.add_argument("--masses", type=float, nargs=5, default=MASSES, metavar="M",
+                    help="masses of the five particle types (the reference's default is 1 for all)")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--reorder-interval", type=int, default=-1,
                     help="steps between refreshes of the field-tile particle order (-1 automatic, 0 never)")
@@ -214,7 +216,7 @@ def main():
     dims = tuple(args.field)
     n_cells = dims[0] * dims[1] * dims[2]
     n_total = args.total_particles if args.scaling == "strong" else args.particles_per_gpu * world
-    sp = make_params(pa, dims)
+    sp = make_params(pa, dims, args.masses)
 
     # Field: built on rank 0, replicated by ShardedCompute with one broadcast over RCCL;
     # every rank fills its own index range with the seeded scene on the device.
