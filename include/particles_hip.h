@@ -434,6 +434,7 @@ int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks,
  *   0xF000   point of the refresh interval the tile order aims at, in tenths (default 5)
  *   0x10000  cut-off cells of the binned pair term: one-cell reach only
  *   0x20000  cut-off cells: at most 20 per axis
+ *   0x400000 the streaming kernels fetch the 16-byte cells instead of the copy packed to 12 bytes
  *   0x80000  the streaming step updates the particle arrays in place instead of ping-pong
  *   0x40000  tests only: the next refresh of the particle order scatters with other keys than its
  *            histogram counted, which the kernel reports as PCL_ERR_DEVICE (the state is then unusable) */

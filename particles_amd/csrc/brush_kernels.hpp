@@ -132,8 +132,8 @@ __global__ __launch_bounds__(kBlockThreads) void brush_select_kernel(
 // Cursor::mouse_moved: src/cursor.rs:79-103.
 __global__ __launch_bounds__(kBlockThreads) void brush_apply_kernel(
     BrushInput by_value, const BrushInput* __restrict__ from_device, FieldGeometry G,
-    f32x4* __restrict__ field, const BrushState* __restrict__ state, const uint32_t* __restrict__ sel_index,
-    const f32x4* __restrict__ sel_vector, uint32_t* error)
+    f32x4* __restrict__ field, float* __restrict__ field3, const BrushState* __restrict__ state,
+    const uint32_t* __restrict__ sel_index, const f32x4* __restrict__ sel_vector, uint32_t* error)
 {
     const BrushInput in = from_device ? *from_device : by_value;
     if (!brush_record_valid(in)) {
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(kBlockThreads) void brush_apply_kernel(
         }
         out.w = 1.0f;                                                           // src/grid.rs:97-103
         field[c] = out;
+        if (field3) { field3[3u * c] = out.x; field3[3u * c + 1u] = out.y; field3[3u * c + 2u] = out.z; }   // the packed copy
     }
 }
 

@@ -18,7 +18,7 @@ hipStream_t stream_of(const pcl_compute* h);
 // Sizes the handle's field for n_cells cells (as a whole-field replace does) and returns its
 // device address, so that a collective can deliver the cells straight into it.
 int field_for_write(pcl_compute* h, size_t n_cells, void** dev_field);
-void* field_of(const pcl_compute* h);
+void* field_of(pcl_compute* h);                          // for writing: the packed copy is rebuilt before the next step
 size_t cells_of(const pcl_compute* h);
 // Reduces the diagnostics of the latest state on the handle's stream (unless a fused per-step
 // result is current) and returns the device address of the 48-byte record.

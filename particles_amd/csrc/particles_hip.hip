@@ -153,6 +153,11 @@ struct pcl_compute {
 
     pcl::f32x4* field = nullptr;
     size_t n_cells = 0;
+    // second copy of the field packed to 12 bytes per cell, what the streaming kernels fetch from
+    // (fetch_cell); built before a streaming step when stale, kept equal by brush and indexed patches
+    float* field3 = nullptr;
+    size_t field3_capacity = 0;
+    bool field3_valid = false;
     // field brush (src/cursor.rs): selection made by mouse_down, used by mouse_moved
     bool brush_down = false;
     pcl::BrushState* d_brush_state = nullptr;
@@ -278,8 +283,41 @@ int reserve_field(pcl_compute* h, size_t n_cells)
     if (h->field) (void)hipFree(h->field);
     h->field = nullptr;
     h->field_capacity = 0;
+    h->field3_valid = false;
     PCL_HIP_TRY(hipMalloc((void**)&h->field, n_cells * sizeof(pcl::f32x4)));
     h->field_capacity = n_cells;
+    return PCL_OK;
+}
+
+// The packed copy pays once the field no longer sits in the vector L1 under the particle streams
+// (tuning bit 0x400000 turns it off).
+bool use_field3(const pcl_compute* h)
+{
+    return h->n_cells * sizeof(pcl::f32x4) > kAutoReorderMinFieldBytes && (h->variant & 0x400000u) == 0;
+}
+
+// Packed copy for the next streaming launch: null when not used, else brought up to date.
+int current_field3(pcl_compute* h, const float** out)
+{
+    *out = nullptr;
+    if (!use_field3(h)) return PCL_OK;
+    if (h->field3_capacity < h->n_cells) {
+        PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->field3) (void)hipFree(h->field3);
+        h->field3 = nullptr;
+        h->field3_capacity = 0;
+        h->field3_valid = false;
+        PCL_HIP_TRY(hipMalloc((void**)&h->field3, h->field_capacity * 3 * sizeof(float)));
+        h->field3_capacity = h->field_capacity;
+    }
+    if (!h->field3_valid) {
+        const size_t blocks = (h->n_cells + pcl::kBlockThreads - 1) / pcl::kBlockThreads;
+        hipLaunchKernelGGL(pcl::pack_field3_kernel, dim3((uint32_t)std::min<size_t>(blocks, 4096)), dim3(pcl::kBlockThreads), 0,
+                           h->stream, (const pcl::f32x4*)h->field, 0ull, (unsigned long long)h->n_cells, h->field3);
+        PCL_HIP_TRY(hipGetLastError());
+        h->field3_valid = true;
+    }
+    *out = h->field3;
     return PCL_OK;
 }
 
@@ -835,6 +873,9 @@ int do_step_impl(pcl_compute* h, int* kind)
             if (h->step_diag)
                 if (int rc = reserve_partials(h, grid)) return rc;
             sa.field = h->field;
+            const float* packed = nullptr;
+            if (int rc = current_field3(h, &packed)) return rc;
+            sa.field3 = packed;
             sa.partials = h->d_partials;
             const size_t lds_bytes = pcl::scatter_lds_bytes(T.n_bins);
             if (h->step_diag)
@@ -886,6 +927,9 @@ int do_step_impl(pcl_compute* h, int* kind)
             a.partials = h->d_partials;
             a.hist = h->d_hist;
             a.hist_groups = pcl::kCursorGroups;
+            const float* packed = nullptr;
+            if (int rc = current_field3(h, &packed)) return rc;
+            a.field3 = packed;
             a.runs = (count && !h->runs_pending) ? h->d_runs : nullptr;
             const bool lds = use_lds_field(h);
             a.lds_cells = lds ? (uint32_t)h->n_cells : 0u;
@@ -1086,6 +1130,7 @@ int check_range(size_t first, size_t count, size_t n, const char* what)
 int upload_field(pcl_compute* h, size_t first_cell, const void* src, size_t count, bool from_device)
 {
     if (count == 0) return PCL_OK;
+    h->field3_valid = false;
     PCL_HIP_TRY(hipMemcpyAsync(h->field + first_cell, src, count * sizeof(pcl::f32x4),
                                from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                                h->stream));
@@ -1159,7 +1204,7 @@ int brush_mouse_moved(pcl_compute* h, const pcl_brush_input* host_in, const void
     const uint32_t grid = std::min<uint32_t>(linear_grid(h, h->n_cells), 1024u);
     hipLaunchKernelGGL(pcl::brush_apply_kernel, dim3(grid), dim3(pcl::kBlockThreads), 0, h->stream,
                        brush_input_of(host_in), static_cast<const pcl::BrushInput*>(dev_in), G, h->field,
-                       (const pcl::BrushState*)h->d_brush_state, (const uint32_t*)h->d_brush_index,
+                       h->field3_valid ? h->field3 : nullptr, (const pcl::BrushState*)h->d_brush_state, (const uint32_t*)h->d_brush_index,
                        (const pcl::f32x4*)h->d_brush_vector, h->d_error);
     PCL_HIP_TRY(hipGetLastError());
     return PCL_OK;
@@ -1173,7 +1218,11 @@ int fail(int code, const std::string& message) { return ::fail(code, message); }
 int make_current(const pcl_compute* h) { return bind(h); }
 int device_of(const pcl_compute* h) { return h->device; }
 hipStream_t stream_of(const pcl_compute* h) { return h->stream; }
-void* field_of(const pcl_compute* h) { return h->field; }
+void* field_of(pcl_compute* h)
+{
+    h->field3_valid = false;   // handed out for writing (collectives deliver cells straight into it)
+    return h->field;
+}
 size_t cells_of(const pcl_compute* h) { return h->n_cells; }
 bool pair_term_active(const pcl_compute* h) { return !pair_term_inert(h->params); }
 bool step_diagnostics_enabled(const pcl_compute* h) { return h->step_diag; }
@@ -1187,6 +1236,7 @@ int field_for_write(pcl_compute* h, size_t n_cells, void** dev_field)
     if (int rc = reserve_field(h, n_cells)) return rc;
     if (n_cells != h->n_cells) h->brush_down = false;   // a selection indexes the field it was made on
     h->n_cells = n_cells;
+    h->field3_valid = false;   // the caller is about to write the cells
     *dev_field = h->field;
     return PCL_OK;
 }
@@ -1235,6 +1285,7 @@ int pcl_destroy(pcl_compute* h)
     if (h->own_stream && h->own_stream != h->stream) (void)hipStreamSynchronize(h->own_stream);
     free_particles(h);
     if (h->field) (void)hipFree(h->field);
+    if (h->field3) (void)hipFree(h->field3);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_partials) (void)hipFree(h->d_partials);
     if (h->d_diag) (void)hipFree(h->d_diag);
@@ -1455,8 +1506,8 @@ int pcl_patch_force_grid_indexed(pcl_compute* h, const uint32_t* cell_indices, c
     if (e == hipSuccess) e = hipMemcpyAsync(d_index, cell_indices, count * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(pcl::patch_field_kernel, dim3(linear_grid(h, count)), dim3(pcl::kBlockThreads), 0, h->stream,
-                           h->field, (unsigned long long)h->n_cells, (const uint32_t*)d_index,
-                           (const pcl::f32x4*)d_cells, (unsigned long long)count);
+                           h->field, h->field3_valid ? h->field3 : nullptr, (unsigned long long)h->n_cells,
+                           (const uint32_t*)d_index, (const pcl::f32x4*)d_cells, (unsigned long long)count);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1471,8 +1522,9 @@ int pcl_patch_force_grid_indexed_device(pcl_compute* h, const void* dev_cell_ind
     if (count == 0) return PCL_OK;
     PCL_REQUIRE(dev_cell_indices != nullptr && dev_cells != nullptr, "pcl_patch_force_grid_indexed_device: null argument");
     hipLaunchKernelGGL(pcl::patch_field_kernel, dim3(linear_grid(h, count)), dim3(pcl::kBlockThreads), 0, h->stream,
-                       h->field, (unsigned long long)h->n_cells, reinterpret_cast<const uint32_t*>(dev_cell_indices),
-                       reinterpret_cast<const pcl::f32x4*>(dev_cells), (unsigned long long)count);
+                       h->field, h->field3_valid ? h->field3 : nullptr, (unsigned long long)h->n_cells,
+                       reinterpret_cast<const uint32_t*>(dev_cell_indices), reinterpret_cast<const pcl::f32x4*>(dev_cells),
+                       (unsigned long long)count);
     PCL_HIP_TRY(hipGetLastError());
     return PCL_OK;
 }

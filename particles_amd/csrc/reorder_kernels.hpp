@@ -345,6 +345,7 @@ __global__ __launch_bounds__(kStreamThreads) void reorder_scatter_kernel(Reorder
 struct StepScatterArgs {
     ReorderArgs r;
     const f32x4* __restrict__ field;
+    const float* __restrict__ field3;   // the field packed to 12 bytes per cell, or null (fetch_cell)
     DiagPartial* partials;
 };
 
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(kStreamThreads) void step_scatter_kernel(StepScatte
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k < live) {
-            const f32x4 f = sa.field[cell_index(U, V[0][k], V[1][k], V[2][k])];
+            const f32x4 f = fetch_cell(sa.field, sa.field3, cell_index(U, V[0][k], V[1][k], V[2][k]));
             const float m = mass_of(U, (t4 >> (8 * k)) & 0xFFu);
             float x = V[0][k], y = V[1][k], z = V[2][k], vx = V[3][k], vy = V[4][k], vz = V[5][k];
             integrate(U, f.x, f.y, f.z, m, 0.0f, 0.0f, 0.0f, x, y, z, vx, vy, vz);

@@ -318,6 +318,23 @@ __device__ __forceinline__ uint32_t lds_rank_add(uint32_t* counters, uint32_t ke
     return active ? atomicAdd(&counters[key], 1u) : 0u;
 }
 
+// The streaming kernels fetch the field from a second copy packed to 12 bytes per cell (x, y, z;
+// the shader reads only .xyz, wgsl:148) when the host supplies one: a quarter fewer cache lines
+// under the same particles (measured on 2^28 particles, 1024^2 field: plain step 2.351 against
+// 2.368 ms).  Null: the 16-byte cells.
+struct Cell3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ f32x4 fetch_cell(const f32x4* __restrict__ field, const float* __restrict__ field3, uint32_t c)
+{
+    if (field3) {
+        const Cell3 v = reinterpret_cast<const Cell3*>(field3)[c];
+        return f32x4{v.x, v.y, v.z, 1.0f};
+    }
+    return field[c];
+}
+
 struct StreamArgs {
     const float* src[6];   // dst may equal src (in-place update): no __restrict__ on the state arrays
     float* dst[6];
@@ -329,6 +346,7 @@ struct StreamArgs {
     uint32_t* hist;         // global tile histogram when COUNT: counter of bin b for tile t is hist[(t % hist_groups) * n_bins + b]
     uint32_t hist_groups;
     uint32_t* runs;         // when COUNT: total over blocks of the bins each block touched (may be null)
+    const float* __restrict__ field3;   // the field packed to 12 bytes per cell, or null (fetch_cell)
 };
 
 template <bool NT>
@@ -404,7 +422,7 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_kernel(StreamArgs 
         if (threadIdx.x == 0) touched_sh = 0u;
         __syncthreads();
     }
-    auto fetch = [&](uint32_t c) -> f32x4 { return FIELD_LDS ? lds_field[c] : a.field[c]; };
+    auto fetch = [&](uint32_t c) -> f32x4 { return FIELD_LDS ? lds_field[c] : fetch_cell(a.field, a.field3, c); };
 
     DiagAcc acc;
     if (DIAG) acc.init();
@@ -536,7 +554,7 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_fused_kernel(Strea
         for (uint32_t s = 0; s < sub_steps; ++s) {
             f32x4 F[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) F[k] = a.field[cell_index(U, X[k], Y[k], Z[k])];
+            for (int k = 0; k < 4; ++k) F[k] = fetch_cell(a.field, a.field3, cell_index(U, X[k], Y[k], Z[k]));
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float x = X[k], y = Y[k], z = Z[k], vx = VX[k], vy = VY[k], vz = VZ[k];
@@ -562,7 +580,7 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_fused_kernel(Strea
         float vx = a.src[3][tail], vy = a.src[4][tail], vz = a.src[5][tail];
         const float m = mass_of(U, a.ty[tail]);
         for (uint32_t s = 0; s < sub_steps; ++s) {
-            const f32x4 f = a.field[cell_index(U, x, y, z)];
+            const f32x4 f = fetch_cell(a.field, a.field3, cell_index(U, x, y, z));
             integrate(U, f.x, f.y, f.z, m, 0.0f, 0.0f, 0.0f, x, y, z, vx, vy, vz);
         }
         a.dst[0][tail] = x; a.dst[1][tail] = y; a.dst[2][tail] = z;
@@ -959,19 +977,36 @@ __global__ __launch_bounds__(kBlockThreads) void cell_index_kernel(
     }
 }
 
+// field3[3c .. 3c+2] = field[c].xyz for the cells [first, first + count).
+__global__ __launch_bounds__(kBlockThreads) void pack_field3_kernel(
+    const f32x4* __restrict__ field, unsigned long long first, unsigned long long count, float* __restrict__ field3)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x; i < count; i += stride) {
+        const f32x4 c = field[first + i];
+        float* o = field3 + 3ull * (first + i);
+        o[0] = c.x; o[1] = c.y; o[2] = c.z;
+    }
+}
+
 // ------------------------------------------------ indexed field patch K5
 
 // field[index[i]] = cells[i]: brush edits rewrite a list of cells
 // (src/cursor.rs:79-103 writes grid.grid[ix] for ix in modify_vector_indices).
+// `field3` (may be null): the packed copy, kept equal.
 __global__ __launch_bounds__(kBlockThreads) void patch_field_kernel(
-    f32x4* __restrict__ field, unsigned long long n_cells, const uint32_t* __restrict__ index,
-    const f32x4* __restrict__ cells, unsigned long long count)
+    f32x4* __restrict__ field, float* __restrict__ field3, unsigned long long n_cells,
+    const uint32_t* __restrict__ index, const f32x4* __restrict__ cells, unsigned long long count)
 {
     const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
     for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x;
          i < count; i += stride) {
         const uint32_t c = index[i];
-        if (c < n_cells) field[c] = cells[i];
+        if (c < n_cells) {
+            const f32x4 v = cells[i];
+            field[c] = v;
+            if (field3) { field3[3ull * c] = v.x; field3[3ull * c + 1] = v.y; field3[3ull * c + 2] = v.z; }
+        }
     }
 }
 

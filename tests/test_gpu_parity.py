@@ -639,3 +639,44 @@ def test_config2_16m_particles_slices_match_oracle(oracle, n, dims, expect):
             assert np.array_equal(c.debug_cell_indices(first, 4000), oracle.cell_indices(sp, want, g.shape[0]))
         d = c.diagnostics()
         assert d["count"] == n
+
+
+def test_config5_64m_particles_with_per_frame_brush_edits(oracle):
+    """BASELINE configuration 5 at full size on one GPU: 2^26 particles, 1024^2
+    field, every frame a brush stroke on the device field (src/cursor.rs:79-116,
+    Shift mode) and one update with fused diagnostics, 14 frames (one refresh
+    cycle of the tile order); the field bytes and slices of the particles
+    against the oracle applying the same strokes and stepping the same global
+    indices."""
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = (1024, 1024, 1)
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    g = scene_swirl_field(1024, 1024, 1, 10.0, seed=5)
+    n = 1 << 26
+    frames = 14
+    em = pa.EditMode(mode="shift", falloff="linear", falloff_dist=1.0, strength=1.0)
+    m = oracle.edit_mode("shift", True, "linear", 1.0, 1.0)
+    firsts = (0, 33333333, n - 3000)
+    slices = [oracle.synth_particles(3000, seed=77, first_global_index=f, pos_extent=20.0, vel_extent=10.0) for f in firsts]
+    with pa.Compute.new(pa.empty_particles(0), g) as c:
+        c.update_sim_params(sp)
+        c.enable_step_diagnostics(True)
+        c.generate_particles(n, seed=77, pos_extent=20.0, vel_extent=10.0)
+        brush = pa.DeviceBrush(c, em)
+        brush.mouse_down((0.0, 0.0, 0.0))
+        idx, vec = oracle.brush_mouse_down(sp, g, (0.0, 0.0, 0.0), 1.0)
+        assert idx.size > 5000                                   # a stroke of several thousand cells
+        want_g = g
+        for k in range(frames):
+            cursor = (0.3 * np.cos(0.05 * k), 0.3 * np.sin(0.05 * k), 0.0)
+            brush.mouse_moved(cursor)
+            c.compute()
+            want_g = oracle.brush_mouse_moved(sp, want_g, m, idx, vec, (0.0, 0.0, 0.0), cursor)
+            slices = [oracle.step(sp, s, want_g, mode=oracle.MODE_SKIP_INERT) for s in slices]
+        assert c.reorder_count >= 2
+        assert c.read_force_grid().tobytes() == want_g.tobytes()
+        for f, want in zip(firsts, slices):
+            assert_particles_bit_equal(c.read_particles(f, 3000), want, f"slice at {f}")
+        d = c.diagnostics()
+        assert d["count"] == n

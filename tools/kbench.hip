@@ -341,7 +341,7 @@ __global__ void generate_sorted_kernel(StateSoA s, uint8_t* ty, unsigned long lo
 
 struct Ctx {
     unsigned long long n;
-    StreamArgs fwd, bwd;
+    StreamArgs fwd{}, bwd{};   // zero: no packed field copy, no histogram
     StepUniforms U;
     hipEvent_t e0, e1;
     StateSoA s0;
