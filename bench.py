@@ -163,7 +163,7 @@ def main():
     ap.add_argument("--reorder-interval", type=int, default=-1,
                     help="steps between refreshes of the field-tile particle order (-1 automatic, 0 never)")
     ap.add_argument("--grid-blocks", type=int, default=0)
-    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--variant", type=lambda s: int(s, 0), default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch-timing", choices=("on", "off"), default="on",
                     help="off: no per-launch event pairs (the roofline then uses the whole region's time per step)")
