@@ -405,20 +405,20 @@ constexpr uint32_t kRunSlots = 256;   // counters of StreamArgs::runs
 // (LDS counters per persistent block, one global atomic per non-empty bin), so
 // that the next step can be a step_scatter_kernel without a counting pass.
 // FIELD_LDS and COUNT are exclusive (both use the dynamic LDS).
-template <bool DIAG, bool NT, bool FIELD_LDS, bool COUNT = false>
-__global__ __launch_bounds__(kStreamThreads) void step_stream_kernel(StreamArgs a, StepUniforms U, TileMap T)
+template <bool DIAG, bool NT, bool FIELD_LDS, bool COUNT = false, int BLOCK = kStreamThreads>
+__global__ __launch_bounds__(BLOCK) void step_stream_kernel(StreamArgs a, StepUniforms U, TileMap T)
 {
     // Small fields (<= 64 KiB; the host decides when it pays) are staged in LDS once per persistent block;
     // larger ones are fetched through L2 / Infinity Cache.
     extern __shared__ __attribute__((aligned(16))) f32x4 lds_field[];
     uint32_t* lds_hist = reinterpret_cast<uint32_t*>(lds_field);
     if (FIELD_LDS) {
-        for (uint32_t c = threadIdx.x; c < a.lds_cells; c += kStreamThreads) lds_field[c] = a.field[c];
+        for (uint32_t c = threadIdx.x; c < a.lds_cells; c += BLOCK) lds_field[c] = a.field[c];
         __syncthreads();
     }
     __shared__ uint32_t touched_sh;
     if (COUNT) {
-        for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) lds_hist[b] = 0u;
+        for (uint32_t b = threadIdx.x; b < T.n_bins; b += BLOCK) lds_hist[b] = 0u;
         if (threadIdx.x == 0) touched_sh = 0u;
         __syncthreads();
     }
@@ -428,13 +428,13 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_kernel(StreamArgs 
     if (DIAG) acc.init();
 
     const unsigned long long n_groups = a.n / 4ull;
-    const unsigned long long n_tiles = (n_groups + kStreamThreads - 1) / kStreamThreads;
+    const unsigned long long n_tiles = (n_groups + BLOCK - 1) / BLOCK;
     for (unsigned long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const unsigned long long g = t * kStreamThreads + threadIdx.x;
+        const unsigned long long g = t * BLOCK + threadIdx.x;
         if (g >= n_groups) break;
         // the tile's groups, and this lane's byte offset inside the tile
-        const unsigned long long g0 = t * kStreamThreads;
-        const uint32_t groups = (uint32_t)(n_groups - g0 < (unsigned long long)kStreamThreads ? n_groups - g0 : kStreamThreads);
+        const unsigned long long g0 = t * BLOCK;
+        const uint32_t groups = (uint32_t)(n_groups - g0 < (unsigned long long)BLOCK ? n_groups - g0 : BLOCK);
         const uint32_t lane16 = threadIdx.x * 16u;
         f32x4 X, Y, Z, VX, VY, VZ;
         uint32_t t4;
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_kernel(StreamArgs 
         // one tile per block in a counting launch; the ragged tail (block 0) counts with tile 0
         const uint32_t count_group = blockIdx.x % a.hist_groups;
         uint32_t touched = 0u;
-        for (uint32_t b = threadIdx.x; b < T.n_bins; b += kStreamThreads) {
+        for (uint32_t b = threadIdx.x; b < T.n_bins; b += BLOCK) {
             const uint32_t c = lds_hist[b];
             if (c) { atomicAdd(&a.hist[count_group * T.n_bins + b], c); ++touched; }
         }
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_kernel(StreamArgs 
             if (threadIdx.x == 0) atomicAdd(&a.runs[blockIdx.x % kRunSlots], touched_sh);
         }
     }
-    if (DIAG) block_reduce_store<kStreamThreads>(acc, a.partials + blockIdx.x);
+    if (DIAG) block_reduce_store<BLOCK>(acc, a.partials + blockIdx.x);
 }
 
 // Several consecutive updates of every particle in one pass over the arrays:

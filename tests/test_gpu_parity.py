@@ -63,6 +63,56 @@ def test_stream_kernel_ragged_sizes(oracle, n):
         assert np.array_equal(c.debug_cell_indices(), oracle.cell_indices(sp, want, g.shape[0]))
 
 
+@pytest.mark.parametrize("block_sel,per_cu", [(0, 2), (1, 5), (2, 10), (3, 12), (1, 15), (0, 1)])
+@pytest.mark.parametrize("n,diag", [(100003, False), (4099, False), (1025, True)])
+def test_plain_step_launch_shapes_give_identical_results(oracle, block_sel, per_cu, n, diag):
+    """The plain streaming step in blocks of 512/256/128/64 threads with a cap on the resident
+    blocks per CU (what large sets use automatically): ragged sizes, bit-equal to the oracle;
+    with fused diagnostics only the 512-thread shape applies (the others fall back to it)."""
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = (16, 8, 4)
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    g = scene_swirl_field(16, 8, 4, 10.0, seed=7)
+    p = oracle.synth_particles(n, seed=77 + n, pos_extent=20.0, vel_extent=10.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        c.set_tuning(0, (block_sel << 28) | (per_cu << 24))
+        c.enable_step_diagnostics(diag)
+        for _ in range(3):
+            c.compute()
+        want = oracle.run(sp, p, g, 3, mode=oracle.MODE_SKIP_INERT)
+        assert_particles_bit_equal(c.read_particles(), want, f"block_sel={block_sel} per_cu={per_cu} n={n}")
+        if diag:
+            d = c.diagnostics()      # with step diagnostics on: the record the last step accumulated
+            dw = oracle.diagnostics(sp, want)
+            assert d["count"] == dw["count"] == n
+            assert abs(d["kinetic_energy"] - dw["kinetic_energy"]) <= 1e-12 * dw["kinetic_energy"]
+            assert np.array_equal(d["pos_max"], dw["pos_max"]) and np.array_equal(d["pos_min"], dw["pos_min"])
+
+
+def test_automatic_launch_shape_of_large_sets_is_bit_exact(oracle):
+    """From 2^26 particles on the plain step runs in 256-thread blocks, five to a CU; a ragged
+    count just above the switch, field fetched through the caches in caller order (no tile order),
+    slices against the oracle."""
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = (64, 64, 1)
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    g = scene_swirl_field(64, 64, 1, 10.0, seed=11)
+    n = (1 << 26) + 1027
+    with pa.Compute.new(pa.empty_particles(0), g) as c:
+        c.update_sim_params(sp)
+        c.set_reorder_interval(0)
+        c.generate_particles(n, seed=99, pos_extent=20.0, vel_extent=10.0)
+        for _ in range(3):
+            c.compute()
+        for first in (0, 33554432 - 500, n - 3000):
+            p = oracle.synth_particles(3000, seed=99, first_global_index=first, pos_extent=20.0, vel_extent=10.0)
+            want = oracle.run(sp, p, g, 3, mode=oracle.MODE_SKIP_INERT)
+            assert_particles_bit_equal(c.read_particles(first, 3000), want, f"slice at {first}")
+
+
 def test_empty_particle_set():
     sp, p, g = default_scene()
     with pa.Compute.new(p[:0], g) as c:

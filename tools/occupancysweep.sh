@@ -1,0 +1,22 @@
+#!/bin/bash
+# Plain step kernel by block size and resident blocks per CU (tuning bits 24-30 of the variant word).
+#   bash tools/occupancysweep.sh [bench args...]
+set -u
+run() {  # label, variant
+  timeout -k 10 120 python bench.py --steps 48 --warmup 12 --no-cpu-baseline --fused-steps 0 --variant $2 "${EXTRA[@]}" > /tmp/occ.json 2>/tmp/occ.err || { echo "variant $2 failed"; tail -n 3 /tmp/occ.err; exit 1; }
+  python - "$1" <<'PY'
+import json, sys
+d = json.load(open("/tmp/occ.json"))
+k = {x["kernel"]: x["avg_ms"] for x in d["roofline"]["kernels"]}
+f = lambda v: "   —  " if v is None else f"{v:.4f}"
+print(f"{sys.argv[1]:40s} plain {f(k['step_stream_kernel'])} ms  count {f(k['step_stream_kernel+count'])}  scatter {f(k['step_scatter_kernel'])}  whole {d['ms_per_step']:.4f} ms/step", flush=True)
+PY
+}
+EXTRA=("$@")
+sizes=(512 256 128 64 384 192 320 448)
+run "default (512 threads, no cap)" 0
+for spec in "0 2" "0 3" "1 4" "1 5" "1 6" "4 2" "4 3" "4 4" "5 5" "5 6" "5 7" "5 8" "6 3" "6 4" "6 5" "7 2" "7 3" "2 8" "2 10" "2 12"; do
+  set -- $spec
+  run "block ${sizes[$1]}, $2 per CU = $(( ${sizes[$1]} / 64 * $2 )) waves" $(( ($1 << 28) | ($2 << 24) ))
+done
+run "default (512 threads, no cap)" 0
