@@ -1,7 +1,7 @@
 #!/bin/bash
 # Refresh-interval sweep on the headline workload: bash tools/intervalsweep.sh
 set -e
-for iv in 6 8 10 12 14 16; do
+for iv in ${INTERVALS:-6 8 10 12 14 16}; do
   steps=$((iv * 10)); warm=$((iv * 2))
   timeout -k 10 120 python bench.py --no-cpu-baseline --fused-steps 0 --reorder-interval $iv --steps $steps --warmup $warm > gpurun_out/iv_${iv}.json 2>/dev/null
   python -c "
