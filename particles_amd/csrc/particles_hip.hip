@@ -474,15 +474,16 @@ size_t occupancy_pad(uint32_t cap, size_t used)
     return per_block > used ? per_block : used;
 }
 
+// More than 64 KiB of dynamic LDS (caps of one or two blocks per CU) has to be allowed per kernel
+// and per device, once.
 template <typename K>
-int allow_large_lds(K kernel)
+int allow_large_lds(K kernel, int device, size_t bytes)
 {
-    static bool done = false;   // per kernel instantiation; every device of the process runs the same code object
-    if (!done) {
-        PCL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        160 * 1024 - 1024));
-        done = true;
-    }
+    static bool done[64] = {};   // per kernel instantiation
+    if (bytes <= 64u * 1024u || device < 0 || device >= 64 || done[device]) return PCL_OK;
+    PCL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024 - 1024));
+    done[device] = true;
     return PCL_OK;
 }
 
@@ -498,9 +499,10 @@ int launch_plain_shaped(pcl_compute* h, const pcl::StreamArgs& a, const pcl::Ste
         if (int rc = reserve_partials(h, (uint32_t)tiles)) return rc;
     pcl::StreamArgs args = a;
     args.partials = h->d_partials;
-    if (int rc = allow_large_lds(pcl::step_stream_kernel<DIAG, NT, false, false, BLOCK>)) return rc;
+    const size_t pad = occupancy_pad(cap, 0);
+    if (int rc = allow_large_lds(pcl::step_stream_kernel<DIAG, NT, false, false, BLOCK>, h->device, pad)) return rc;
     hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, false, false, BLOCK>), dim3((uint32_t)tiles), dim3(BLOCK),
-                       occupancy_pad(cap, 0), h->stream, args, U, T);
+                       pad, h->stream, args, U, T);
     PCL_HIP_TRY(hipGetLastError());
     return PCL_OK;
 }
