@@ -60,6 +60,23 @@ __global__ __launch_bounds__(BLOCK) void deep_capped_kernel(Arrays a)
     for (int k = 0; k < 6; ++k) st(a.dst[k] + g, v[k]);
 }
 
+// deep, loads as LDS-DMA (global_load_lds_dwordx4: no register destination), every lane then reads its own
+// 16 bytes back from LDS and stores them; one tile per block, `pad` bytes of extra dynamic LDS cap the residency
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void deep_glds_kernel(Arrays a)
+{
+    extern __shared__ __attribute__((aligned(16))) f32x4 stage[];   // [6][BLOCK]
+    const unsigned long long g = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= a.n4) return;   // n4 is a multiple of BLOCK here: whole waves leave together
+    const unsigned wave_base = threadIdx.x & ~63u;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        __builtin_amdgcn_global_load_lds(a.src[k] + g, (__attribute__((address_space(3))) void*)(stage + k * BLOCK + wave_base), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 6; ++k) st(a.dst[k] + g, stage[k * BLOCK + threadIdx.x]);
+}
+
 // every lane: one group of ONE array; consecutive blocks take the six arrays of one tile in turn,
 // so the chip sees the same twelve streams advance together, from waves that hold one access each
 template <int BLOCK>
@@ -205,6 +222,18 @@ int main(int argc, char** argv)
         run(name, [&] { hipLaunchKernelGGL(deep_capped_kernel<256>, dim3((unsigned)(n4 / 256)), dim3(256), lds, 0, a); });
         snprintf(name, sizeof name, "deep, 512-thread blocks, <= %d per CU", bpc);
         run(name, [&] { hipLaunchKernelGGL(deep_capped_kernel<512>, dim3((unsigned)(n4 / 512)), dim3(512), lds, 0, a); });
+    }
+    for (int bpc : {1, 2, 3, 4, 5, 6}) {
+        const size_t lds = (160u * 1024u) / bpc - 1024u;
+        char name[96];
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&deep_glds_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&deep_glds_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        snprintf(name, sizeof name, "deep by LDS-DMA, 256-thread blocks, <= %d per CU", bpc);
+        run(name, [&] { hipLaunchKernelGGL(deep_glds_kernel<256>, dim3((unsigned)(n4 / 256)), dim3(256), lds, 0, a); });
+        if (bpc <= 3) {
+            snprintf(name, sizeof name, "deep by LDS-DMA, 512-thread blocks, <= %d per CU", bpc);
+            run(name, [&] { hipLaunchKernelGGL(deep_glds_kernel<512>, dim3((unsigned)(n4 / 512)), dim3(512), lds, 0, a); });
+        }
     }
     for (int bpc : {4, 8, 12, 16, 24, 32}) {
         const size_t lds = (160u * 1024u) / bpc - 512u;
