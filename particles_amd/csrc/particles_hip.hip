@@ -66,7 +66,10 @@ int fail(int code, const std::string& msg)
 
 constexpr size_t kStagingRecords = size_t(1) << 22;  // AoS staging chunk: 4 Mi records = 192 MiB
 constexpr uint32_t kLdsFieldMaxBytes = 64u * 1024u;  // fields up to this size are staged in LDS
-constexpr int kAutoReorderInterval = 12;               // steps between refreshes of the tile order
+// Steps between refreshes of the tile order.  Fixed intervals on the headline workload: whole step 66.1 % of 8 TB/s
+// at 8, 67.0 at 12, 67.2 at 16 and 20, 66.9 at 24; 2^26 particles at initial speeds of 1-100 per axis: 16 within
+// 0.4 % of the best everywhere; 2^24 particles on a 256^2 field: 16-24 best (tools/intervalsweep.sh, driftsweep.sh).
+constexpr int kAutoReorderInterval = 16;
 constexpr size_t kPairWideMinParticles = size_t(1) << 18;   // below: the sort over many cells costs more than the sweep saves
 constexpr size_t kHistEntries = (size_t)pcl::kMaxReorderBins * pcl::kCursorGroups;   // counters (and cursors) in d_hist
 constexpr uint32_t kPairMaxCellsPerAxis = 64;          // cut-off cells per axis (beyond 20: counters in global memory)
