@@ -466,10 +466,10 @@ int launch_finalize(pcl_compute* h, uint32_t n_partials, pcl::DiagOut* dev_out)
 // The memory system of an MI355X delivers less when more waves wait on it than it takes to
 // keep it busy: a copy of the step's twelve streams runs at 5.8 TB/s with every wave slot
 // filled and at 6.4 TB/s with 8 waves per CU (tools/copyshape.hip).  The plain step kernel,
-// whose waves also wait for a field fetch, is fastest at 16-20 waves per CU, from 2^26
-// particles on (below that the full occupancy is as fast or faster).  The number of resident
-// blocks is capped by asking for dynamic LDS the kernel never touches: `cap` blocks fit into a
-// CU's 160 KiB, cap + 1 do not (cap <= 12).
+// whose waves also wait for a field fetch, is fastest at 16-20 waves per CU, fewer than its
+// registers allow (24-28), from 2^26 particles on (below that more waves are as fast or faster).
+// The number of resident blocks is capped by asking for dynamic LDS the kernel never touches:
+// `cap` blocks fit into a CU's 160 KiB, cap + 1 do not (cap <= 12).
 size_t occupancy_pad(uint32_t cap, size_t used)
 {
     if (cap == 0 || cap > 12) return used;
@@ -493,7 +493,8 @@ int allow_large_lds(K kernel, int device, size_t bytes)
 // Plain streaming step (field through the caches, no histogram) in blocks of BLOCK threads,
 // one tile of 4 * BLOCK particles per block, at most `cap` blocks per CU (0: whatever fits).
 template <bool DIAG, bool NT, int BLOCK>
-int launch_plain_shaped(pcl_compute* h, const pcl::StreamArgs& a, const pcl::StepUniforms& U, const pcl::TileMap& T, uint32_t cap)
+int launch_plain_shaped(pcl_compute* h, const pcl::StreamArgs& a, const pcl::StepUniforms& U, const pcl::TileMap& T, uint32_t cap,
+                        uint32_t& grid)
 {
     const size_t groups = h->n / 4;
     const size_t tiles = std::max<size_t>(1, (groups + BLOCK - 1) / BLOCK);
@@ -507,6 +508,7 @@ int launch_plain_shaped(pcl_compute* h, const pcl::StreamArgs& a, const pcl::Ste
     hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, false, false, BLOCK>), dim3((uint32_t)tiles), dim3(BLOCK),
                        pad, h->stream, args, U, T);
     PCL_HIP_TRY(hipGetLastError());
+    grid = (uint32_t)tiles;   // what the fold of the partials has to cover
     return PCL_OK;
 }
 
@@ -514,27 +516,27 @@ constexpr size_t kCappedFromParticles = (size_t)1 << 26;
 
 template <bool DIAG, bool NT>
 int launch_stream(pcl_compute* h, const pcl::StreamArgs& a, const pcl::StepUniforms& U, const pcl::TileMap& T,
-                  uint32_t grid, bool lds, bool count)
+                  uint32_t& grid, bool lds, bool count)
 {
     // Shape of the plain step: tuning bits 24-27 = resident blocks per CU (15: no cap), bits 28-30 =
     // block size; all zero = automatic.  A caller-set grid cap (persistent blocks) keeps the one launch shape.
     const uint32_t cap_bits = (h->variant >> 24) & 0xFu, bsel = (h->variant >> 28) & 7u;
     if (!lds && !count && !h->grid_cap) {
         if (cap_bits || bsel) {
-            if (!DIAG || bsel == 0) {
+            {
                 switch (bsel) {
-                case 0: return launch_plain_shaped<DIAG, NT, 512>(h, a, U, T, cap_bits);
-                case 1: return launch_plain_shaped<DIAG, NT, 256>(h, a, U, T, cap_bits);
-                case 2: return launch_plain_shaped<DIAG, NT, 128>(h, a, U, T, cap_bits);
-                case 3: return launch_plain_shaped<DIAG, NT, 64>(h, a, U, T, cap_bits);
+                case 0: return launch_plain_shaped<DIAG, NT, 512>(h, a, U, T, cap_bits, grid);
+                case 1: return launch_plain_shaped<DIAG, NT, 256>(h, a, U, T, cap_bits, grid);
+                case 2: return launch_plain_shaped<DIAG, NT, 128>(h, a, U, T, cap_bits, grid);
+                case 3: return launch_plain_shaped<DIAG, NT, 64>(h, a, U, T, cap_bits, grid);
                 default: break;
                 }
             }
         } else if (!DIAG && h->n >= kCappedFromParticles) {
-            // measured at 2^28 particles, 1024^2 field: 2.28 ms against 2.34 ms with every wave slot filled
-            // (512 threads x 2 per CU: 2.28; 256 x 4: 2.33; 256 x 6: 2.31); 2^26: 0.582 against 0.592 ms;
-            // with fused diagnostics (68 VGPRs, three blocks per CU as it is) a cap only costs
-            return launch_plain_shaped<DIAG, NT, 256>(h, a, U, T, 5);
+            // measured at 2^28 particles, 1024^2 field: 2.28 ms against 2.34 ms with the three 512-thread blocks
+            // per CU that 70 registers allow (512 x 2: 2.28; 256 x 4: 2.33; 256 x 6: 2.31; 256 x 7: 2.33);
+            // 2^26: 0.582 against 0.592 ms; with fused diagnostics (80 registers) a cap only costs
+            return launch_plain_shaped<DIAG, NT, 256>(h, a, U, T, 5, grid);
         }
     }
     if (lds) {

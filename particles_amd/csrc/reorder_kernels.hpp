@@ -349,8 +349,10 @@ struct StepScatterArgs {
     DiagPartial* partials;
 };
 
+// With fused diagnostics the kernel needs 84 registers, four more than three resident blocks of 512 threads
+// allow (6 waves per SIMD = 80 registers); held to 80 it keeps the third block: two blocks per CU cost 20 %.
 template <bool DIAG>
-__global__ __launch_bounds__(kStreamThreads) void step_scatter_kernel(StepScatterArgs sa, StepUniforms U, TileMap T)
+__global__ __launch_bounds__(kStreamThreads, DIAG ? 6 : 1) void step_scatter_kernel(StepScatterArgs sa, StepUniforms U, TileMap T)
 {
     const ReorderArgs& a = sa.r;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];

@@ -405,8 +405,9 @@ constexpr uint32_t kRunSlots = 256;   // counters of StreamArgs::runs
 // (LDS counters per persistent block, one global atomic per non-empty bin), so
 // that the next step can be a step_scatter_kernel without a counting pass.
 // FIELD_LDS and COUNT are exclusive (both use the dynamic LDS).
+// The counting variant with fused diagnostics is held to the 80 registers that three resident blocks allow.
 template <bool DIAG, bool NT, bool FIELD_LDS, bool COUNT = false, int BLOCK = kStreamThreads>
-__global__ __launch_bounds__(BLOCK) void step_stream_kernel(StreamArgs a, StepUniforms U, TileMap T)
+__global__ __launch_bounds__(BLOCK, (DIAG && COUNT) ? 6 : 1) void step_stream_kernel(StreamArgs a, StepUniforms U, TileMap T)
 {
     // Small fields (<= 64 KiB; the host decides when it pays) are staged in LDS once per persistent block;
     // larger ones are fetched through L2 / Infinity Cache.
