@@ -438,7 +438,7 @@ int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks,
  *   0x80000  the streaming step updates the particle arrays in place instead of ping-pong
  *   0xF000000  resident blocks per CU of the plain streaming step (1-12; 15 = as many as fit), and
  *   0x70000000 its block size (0: 512 threads, 1: 256, 2: 128, 3: 64); both zero = automatic
- *            (256 threads, 5 blocks per CU from 2^26 particles on; 512 threads, as many as fit below)
+ *            (256 threads, 5 blocks per CU from 3 * 2^24 particles on; 512 threads, as many as fit below)
  *   0x40000  tests only: the next refresh of the particle order scatters with other keys than its
  *            histogram counted, which the kernel reports as PCL_ERR_DEVICE (the state is then unusable) */
 int pcl_set_tuning(pcl_compute* h, uint32_t grid_blocks, uint32_t variant);

@@ -467,7 +467,7 @@ int launch_finalize(pcl_compute* h, uint32_t n_partials, pcl::DiagOut* dev_out)
 // keep it busy: a copy of the step's twelve streams runs at 5.8 TB/s with every wave slot
 // filled and at 6.4 TB/s with 8 waves per CU (tools/copyshape.hip).  The plain step kernel,
 // whose waves also wait for a field fetch, is fastest at 16-20 waves per CU, fewer than its
-// registers allow (24-28), from 2^26 particles on (below that more waves are as fast or faster).
+// registers allow (24-28), from about 5 * 10^7 particles on (below that more waves are as fast or faster).
 // The number of resident blocks is capped by asking for dynamic LDS the kernel never touches:
 // `cap` blocks fit into a CU's 160 KiB, cap + 1 do not (cap <= 12).
 size_t occupancy_pad(uint32_t cap, size_t used)
@@ -512,7 +512,7 @@ int launch_plain_shaped(pcl_compute* h, const pcl::StreamArgs& a, const pcl::Ste
     return PCL_OK;
 }
 
-constexpr size_t kCappedFromParticles = (size_t)1 << 26;
+constexpr size_t kCappedFromParticles = (size_t)3 << 24;   // 2^25: 0.3155 uncapped against 0.3165 ms capped; 1.5 * 2^25: 0.4548 against 0.4493
 
 template <bool DIAG, bool NT>
 int launch_stream(pcl_compute* h, const pcl::StreamArgs& a, const pcl::StepUniforms& U, const pcl::TileMap& T,

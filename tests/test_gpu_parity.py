@@ -92,8 +92,8 @@ def test_plain_step_launch_shapes_give_identical_results(oracle, block_sel, per_
 
 
 def test_automatic_launch_shape_of_large_sets_is_bit_exact(oracle):
-    """From 2^26 particles on the plain step runs in 256-thread blocks, five to a CU; a ragged
-    count just above the switch, field fetched through the caches in caller order (no tile order),
+    """From 3 * 2^24 particles on the plain step runs in 256-thread blocks, five to a CU; a ragged
+    count above the switch, field fetched through the caches in caller order (no tile order),
     slices against the oracle."""
     sp = pa.SimParams()
     sp.delta_t = DT
