@@ -512,31 +512,40 @@ int launch_plain_shaped(pcl_compute* h, const pcl::StreamArgs& a, const pcl::Ste
     return PCL_OK;
 }
 
+// Block size and residency cap of the plain streaming step (no LDS field, no histogram) for this handle.
+struct PlainShape {
+    uint32_t block;   // threads per block
+    uint32_t cap;     // resident blocks per CU, 0 = as many as fit
+};
+
 constexpr size_t kCappedFromParticles = (size_t)3 << 24;   // 2^25: 0.3155 uncapped against 0.3165 ms capped; 1.5 * 2^25: 0.4548 against 0.4493
+
+// Tuning bits 24-27 = resident blocks per CU (15: no cap), bits 28-30 = block size (512 >> value);
+// all zero = automatic.  A caller-set grid cap (persistent blocks) keeps the one launch shape.
+PlainShape plain_shape(const pcl_compute* h, bool diag)
+{
+    const uint32_t cap_bits = (h->variant >> 24) & 0xFu, bsel = (h->variant >> 28) & 7u;
+    if (cap_bits || bsel) return PlainShape{512u >> std::min(bsel, 3u), cap_bits > 12u ? 0u : cap_bits};
+    // measured at 2^28 particles, 1024^2 field: 2.28 ms against 2.34 ms with the three 512-thread blocks
+    // per CU that 70 registers allow (512 x 2: 2.28; 256 x 4: 2.33; 256 x 6: 2.31; 256 x 7: 2.33);
+    // 2^26: 0.582 against 0.592 ms; with fused diagnostics (80 registers) a cap only costs
+    if (!diag && h->n >= kCappedFromParticles) return PlainShape{256u, 5u};
+    return PlainShape{(uint32_t)pcl::kStreamThreads, 0u};
+}
 
 template <bool DIAG, bool NT>
 int launch_stream(pcl_compute* h, const pcl::StreamArgs& a, const pcl::StepUniforms& U, const pcl::TileMap& T,
                   uint32_t& grid, bool lds, bool count)
 {
-    // Shape of the plain step: tuning bits 24-27 = resident blocks per CU (15: no cap), bits 28-30 =
-    // block size; all zero = automatic.  A caller-set grid cap (persistent blocks) keeps the one launch shape.
-    const uint32_t cap_bits = (h->variant >> 24) & 0xFu, bsel = (h->variant >> 28) & 7u;
     if (!lds && !count && !h->grid_cap) {
-        if (cap_bits || bsel) {
-            {
-                switch (bsel) {
-                case 0: return launch_plain_shaped<DIAG, NT, 512>(h, a, U, T, cap_bits, grid);
-                case 1: return launch_plain_shaped<DIAG, NT, 256>(h, a, U, T, cap_bits, grid);
-                case 2: return launch_plain_shaped<DIAG, NT, 128>(h, a, U, T, cap_bits, grid);
-                case 3: return launch_plain_shaped<DIAG, NT, 64>(h, a, U, T, cap_bits, grid);
-                default: break;
-                }
+        const PlainShape shape = plain_shape(h, DIAG);
+        if (shape.cap || shape.block != (uint32_t)pcl::kStreamThreads) {
+            switch (shape.block) {
+            case 512: return launch_plain_shaped<DIAG, NT, 512>(h, a, U, T, shape.cap, grid);
+            case 256: return launch_plain_shaped<DIAG, NT, 256>(h, a, U, T, shape.cap, grid);
+            case 128: return launch_plain_shaped<DIAG, NT, 128>(h, a, U, T, shape.cap, grid);
+            default: return launch_plain_shaped<DIAG, NT, 64>(h, a, U, T, shape.cap, grid);
             }
-        } else if (!DIAG && h->n >= kCappedFromParticles) {
-            // measured at 2^28 particles, 1024^2 field: 2.28 ms against 2.34 ms with the three 512-thread blocks
-            // per CU that 70 registers allow (512 x 2: 2.28; 256 x 4: 2.33; 256 x 6: 2.31; 256 x 7: 2.33);
-            // 2^26: 0.582 against 0.592 ms; with fused diagnostics (80 registers) a cap only costs
-            return launch_plain_shaped<DIAG, NT, 256>(h, a, U, T, 5, grid);
         }
     }
     if (lds) {
@@ -2027,8 +2036,14 @@ int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks, uint32_t* b
                         uint32_t* particles_per_lane)
 {
     if (!h) return fail(PCL_ERR_INVALID, "null handle");
-    if (grid_blocks) *grid_blocks = stream_grid(h);
-    if (block_threads) *block_threads = pcl::kStreamThreads;
+    uint32_t blocks = stream_grid(h), threads = pcl::kStreamThreads;
+    if (!use_lds_field(h) && !h->grid_cap) {   // the plain step's own shape (the counting and scatter steps keep 512 threads)
+        const PlainShape shape = plain_shape(h, h->step_diag);
+        threads = shape.block;
+        blocks = (uint32_t)std::min<size_t>(std::max<size_t>(1, (h->n / 4 + threads - 1) / threads), 0x7FFFFFFFu);
+    }
+    if (grid_blocks) *grid_blocks = blocks;
+    if (block_threads) *block_threads = threads;
     if (particles_per_lane) *particles_per_lane = pcl::kParticlesPerLane;
     return PCL_OK;
 }
