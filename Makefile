@@ -15,7 +15,9 @@ COMM_OBJ  := build/particles_comm.o
 
 CPPTEST   := tests/cpp/compute_wrapper_test
 
-all: $(LIB) oracle $(CPPTEST)
+FAKE_RCCL := tests/fake_rccl/libfake_rccl.so
+
+all: $(LIB) oracle $(CPPTEST) $(FAKE_RCCL)
 
 # rocPRIM's radix sort in its own object: it compiles slowly and changes rarely
 $(SORT_OBJ): $(SORT_SRC)
@@ -44,6 +46,10 @@ $(LIB): $(MAIN_OBJ) $(SORT_OBJ) $(COMM_OBJ) $(AUTH_OBJ)
 oracle:
 	$(MAKE) -C oracle
 
+# Test infrastructure: a host-staged stand-in for librccl.so that lets several ranks share one GPU
+$(FAKE_RCCL): tests/fake_rccl/fake_rccl.cpp
+	g++ -O1 -std=c++17 -fPIC -shared -Wall -Wextra -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o $@ $< -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -lrt -lpthread
+
 # Host-only program over the C++ mirror of the reference's Compute; plain g++.
 $(CPPTEST): tests/cpp/compute_wrapper_test.cpp include/particles_compute.hpp include/particles_hip.h $(LIB)
 	g++ -O2 -std=c++17 -Wall -Wextra -Iinclude -o $@ $< -Lparticles_amd -lparticles_hip -Wl,-rpath,'$$ORIGIN/../../particles_amd' -Wl,-rpath-link,/opt/rocm/lib
@@ -53,7 +59,7 @@ asm: $(SRC) $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build/particles_hip.s $(SRC) -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt
 
 clean:
-	rm -f $(LIB) $(CPPTEST)
+	rm -f $(LIB) $(CPPTEST) $(FAKE_RCCL)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle asm clean

@@ -10,7 +10,9 @@
  *
  *   gcc -std=c11 -Iinclude examples/group_scene.c -Lparticles_amd -lparticles_hip \
  *       -Wl,-rpath,$PWD/particles_amd -Wl,-rpath-link,/opt/rocm/lib -o group_scene
- *   ./group_scene out.bin [n_devices]
+ *   ./group_scene out.bin [n_devices [device]]
+ * With `device` every rank of the group sits on that one GPU, which RCCL refuses; the tests use it
+ * together with a host-staged stand-in for RCCL (PCL_RCCL_LIBRARY) to run several ranks on one GPU.
  */
 #include "particles_hip.h"
 
@@ -35,12 +37,12 @@ static float unit(unsigned int* s) { return (float)lcg(s) * (1.0f / 16777216.0f)
 
 int main(int argc, char** argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: %s out.bin [n_devices]\n", argv[0]); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: %s out.bin [n_devices [device]]\n", argv[0]); return 2; }
     int n_devices = argc > 2 ? atoi(argv[2]) : pcl_device_count();
     if (n_devices < 1) { fprintf(stderr, "no device: %s\n", pcl_last_error()); return 1; }
     int devices[64];
     if (n_devices > 64) n_devices = 64;
-    for (int i = 0; i < n_devices; ++i) devices[i] = i;
+    for (int i = 0; i < n_devices; ++i) devices[i] = argc > 3 ? atoi(argv[3]) : i;
 
     static pcl_particle particles[N];
     static float field[CELLS][4];

@@ -103,25 +103,47 @@ def diag_of(buf):
             "pos_max": np.array(d.pos_max[:], dtype=np.float32), "pos_min": -np.array(d.neg_pos_min[:], dtype=np.float32)}
 
 
-@pytest.mark.gpu
-def test_plain_c_program_drives_a_group_through_every_collective(tmp_path, oracle):
-    out = tmp_path / "group.bin"
-    text = subprocess.check_output([str(build(tmp_path)), str(out)], text=True, timeout=300)
-    assert "group of " in text          # RCCL prints its version banner on stdout first
-    raw = out.read_bytes()
+def check_program_output(raw, what):
     p, g, r = scene_inputs()
     sp, stream, field, sdiag, pairs, pdiag = model(p, g, r)
     o = 0
     assert raw[o:o + 912] == sp.tobytes(); o += 912
     got = np.frombuffer(raw[o:o + 48 * N], dtype=pa.PARTICLE_DTYPE); o += 48 * N
-    assert_particles_bit_equal(got, stream, "streaming steps + brush + patches over the group")
+    assert_particles_bit_equal(got, stream, f"streaming steps + brush + patches over {what}")
     got_field = np.frombuffer(raw[o:o + 16 * CELLS], dtype=np.float32).reshape(CELLS, 4); o += 16 * CELLS
     assert got_field.tobytes() == field.tobytes() and not np.array_equal(field, g)
     check_diag(diag_of(raw[o:o + 48]), sdiag); o += 48
     got = np.frombuffer(raw[o:o + 48 * N_PAIRS], dtype=pa.PARTICLE_DTYPE); o += 48 * N_PAIRS
-    assert_particles_bit_equal(got, pairs, "pair steps (all-gather) over the group")
+    assert_particles_bit_equal(got, pairs, f"pair steps (all-gather) over {what}")
     check_diag(diag_of(raw[o:o + 48]), pdiag); o += 48
     assert o == len(raw)
+
+
+@pytest.mark.gpu
+def test_plain_c_program_drives_a_group_through_every_collective(tmp_path, oracle):
+    out = tmp_path / "group.bin"
+    text = subprocess.check_output([str(build(tmp_path)), str(out)], text=True, timeout=300)
+    assert "group of " in text          # RCCL prints its version banner on stdout first
+    check_program_output(out.read_bytes(), "the group")
+
+
+FAKE_RCCL = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3, 5])
+def test_group_of_several_ranks_on_one_gpu_over_the_rccl_stand_in(tmp_path, oracle, ranks):
+    """The same program with 2, 3 and 5 ranks, all on GPU 0: RCCL itself refuses that, so the
+    library is pointed (PCL_RCCL_LIBRARY) at tests/fake_rccl, which carries out the same ten
+    entry points through host memory.  What this covers that a world of one cannot: roots and
+    non-roots, index ranges, the padded all-gather of ranges of unequal length, the grouped
+    all-reduces, all equal to the model of ONE device.  RCCL itself is not exercised."""
+    assert os.path.exists(FAKE_RCCL), "make builds tests/fake_rccl/libfake_rccl.so"
+    out = tmp_path / "group.bin"
+    env = dict(os.environ, PCL_RCCL_LIBRARY=FAKE_RCCL)
+    text = subprocess.check_output([str(build(tmp_path)), str(out), str(ranks), "0"], text=True, timeout=300, env=env)
+    assert f"group of {ranks}" in text
+    check_program_output(out.read_bytes(), f"{ranks} ranks on one GPU")
 
 
 @pytest.mark.gpu

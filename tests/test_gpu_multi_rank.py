@@ -54,8 +54,17 @@ def _brush(pa):
     return pa.EditMode(mode="rotate", relative=False, falloff="linear", falloff_dist=2.0, strength=1.5)
 
 
+FAKE_RCCL = os.path.join(HERE, "fake_rccl", "libfake_rccl.so")
+
+
 def _worker(rank, world, port, out_dir, backend="gloo"):
     sys.path.insert(0, os.path.dirname(HERE))
+    collectives = "torch"
+    if backend == "native-stand-in":
+        # the library's own collectives (pcl_comm_*), RCCL replaced by the host-staged stand-in so that the
+        # ranks can share the GPU; the gloo group only carries the unique id and the test's gathers
+        os.environ["PCL_RCCL_LIBRARY"] = FAKE_RCCL
+        backend, collectives = "gloo", "native"
     import torch
     import torch.distributed as dist
     import particles_amd as pa
@@ -75,7 +84,7 @@ def _worker(rank, world, port, out_dir, backend="gloo"):
         sp, g = _scene(pa, O)
         # every rank generates its own range on the device; the field comes from rank 0
         sc = pa.ShardedCompute.new(None, g if rank == 0 else None, n_total=N, seed=31, pos_extent=20.0,
-                                   vel_extent=10.0, device=device)
+                                   vel_extent=10.0, device=device, collectives=collectives)
         assert type(sc.local) is pa.Compute and (sc.first, sc.last) == pa.shard_range(N, rank, world)
         sc.local.set_reorder_interval(3)            # tile order inside every range
         sc.update_sim_params(sp)
@@ -121,6 +130,14 @@ def _worker(rank, world, port, out_dir, backend="gloo"):
 
 def test_three_ranks_on_one_gpu_match_the_unsharded_oracle(tmp_path, oracle):
     _run_and_compare(tmp_path, oracle, WORLD, "gloo")
+
+
+def test_three_ranks_through_the_librarys_collectives_over_the_rccl_stand_in(tmp_path, oracle):
+    """The same script with `collectives="native"`: every broadcast, all-reduce and all-gather is a
+    pcl_comm_* call inside the library, in a world of three (ncclCommInitRank with a shared id), with
+    tests/fake_rccl standing in for RCCL, which does not admit several ranks on one GPU."""
+    assert os.path.exists(FAKE_RCCL), "make builds tests/fake_rccl/libfake_rccl.so"
+    _run_and_compare(tmp_path, oracle, WORLD, "native-stand-in")
 
 
 def test_two_ranks_over_rccl_match_the_unsharded_oracle(tmp_path, oracle):
