@@ -34,8 +34,9 @@ def test_plain_start_with_two_gpus_launches_two_ranks_cpu():
     assert r.stdout.strip() == ""
 
 
-def _run_and_parse(extra, timeout=600):
-    r = subprocess.run([sys.executable, BENCH] + extra, capture_output=True, text=True, timeout=timeout, env=_plain_env())
+def _run_and_parse(extra, timeout=600, env=None):
+    r = subprocess.run([sys.executable, BENCH] + extra, capture_output=True, text=True, timeout=timeout,
+                       env=dict(_plain_env(), **(env or {})))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
@@ -61,6 +62,21 @@ def test_strong_scaling_splits_the_total():
     assert out["n_gpus"] == 2 and out["scaling"] == "strong"
     assert out["config"]["particles_per_gpu"] == 1 << 20           # rank 0's range [0, N/2)
     assert out["final_diagnostics"]["count"] == (1 << 21) + 1
+
+
+@pytest.mark.gpu
+def test_native_collectives_with_two_ranks_on_one_gpu_over_the_rccl_stand_in():
+    """`--collectives native`: field broadcast, brush record and the per-step diagnostics all-reduce are
+    pcl_comm_* calls inside the library; tests/fake_rccl stands in for RCCL (which does not admit two
+    ranks on one GPU), the gloo group only carries the unique id and the benchmark's own timing exchange."""
+    fake = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "libfake_rccl.so")
+    assert os.path.exists(fake), "make builds tests/fake_rccl/libfake_rccl.so"
+    out = _run_and_parse(["--gpus", "2", "--backend", "gloo", "--collectives", "native", "--steps", "6", "--warmup", "2",
+                          "--particles-per-gpu", str(1 << 20), "--field", "256", "256", "1", "--edits",
+                          "--diagnostics", "on", "--no-cpu-baseline", "--fused-steps", "0"],
+                         env={"PCL_RCCL_LIBRARY": fake})
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2           # the library's communicator has both ranks
+    assert out["final_diagnostics"]["count"] == 2 << 20
 
 
 @pytest.mark.gpu
