@@ -5,7 +5,7 @@
 // the 16-byte accesses are spread over lanes, waves and blocks.
 //
 //   hipcc --offload-arch=gfx950 -O3 -o tools/copyshape tools/copyshape.hip
-//   tools/copyshape [log2 n = 28] [repeats = 10]
+//   tools/copyshape [log2 n = 28] [repeats = 10] [stagger bytes = 4096] [anything: capped shapes only]
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -164,7 +164,9 @@ int main(int argc, char** argv)
     const int log2n = argc > 1 ? atoi(argv[1]) : 28;
     const int repeats = argc > 2 ? atoi(argv[2]) : 10;
     const unsigned long long n = 1ull << log2n;
-    const size_t arr = n * 4 + (2u << 20) + 4096;   // the library's stagger
+    const size_t stagger = argc > 3 ? (size_t)atol(argv[3]) : 4096;   // bytes between array starts beyond a multiple of 2 MiB (the library: 4096)
+    const bool capped_only = argc > 4;
+    const size_t arr = n * 4 + (2u << 20) + stagger;
     char* slab = nullptr;
     CK(hipMalloc((void**)&slab, arr * 12));
     CK(hipMemset(slab, 0, arr * 12));
@@ -199,7 +201,14 @@ int main(int argc, char** argv)
         fflush(stdout);
     };
     const unsigned long long n4 = a.n4;
-    printf("n = 2^%d floats per array, 6 arrays in, 6 out (%.2f GB per pass)\n", log2n, bytes / 1e9);
+    printf("n = 2^%d floats per array, 6 arrays in, 6 out (%.2f GB per pass), stagger %zu\n", log2n, bytes / 1e9, stagger);
+    if (capped_only) {   // the two shapes the step kernel uses, for sweeps over the stagger
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&deep_capped_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        run("deep, 256-thread blocks, <= 2 per CU", [&] { hipLaunchKernelGGL(deep_capped_kernel<256>, dim3((unsigned)(n4 / 256)), dim3(256), 160 * 512 - 1024, 0, a); });
+        run("deep, 256-thread blocks, <= 5 per CU", [&] { hipLaunchKernelGGL(deep_capped_kernel<256>, dim3((unsigned)(n4 / 256)), dim3(256), 160 * 1024 / 5 - 1024, 0, a); });
+        run("shallow, 256-thread blocks", [&] { hipLaunchKernelGGL(shallow_kernel<256>, dim3((unsigned)(n4 / 256 * 6)), dim3(256), 0, 0, a); });
+        return 0;
+    }
     run("deep, 256-thread blocks", [&] { hipLaunchKernelGGL(deep_kernel<256>, dim3((unsigned)(n4 / 256)), dim3(256), 0, 0, a); });
     run("deep, 512-thread blocks", [&] { hipLaunchKernelGGL(deep_kernel<512>, dim3((unsigned)(n4 / 512)), dim3(512), 0, 0, a); });
     run("deep, 64-thread blocks", [&] { hipLaunchKernelGGL(deep_kernel<64>, dim3((unsigned)(n4 / 64)), dim3(64), 0, 0, a); });
