@@ -3,7 +3,7 @@
 // growing size and times the same capped copy (256-thread blocks, five per CU) on each.
 //
 //   hipcc --offload-arch=gfx950 -O3 -o tools/placement tools/placement.hip
-//   tools/placement [log2 n = 28] [shift unit in MiB = 2] [shifts = 40] [log2 of the virtual alignment; 0 = hipMalloc]
+//   tools/placement [log2 n = 28] [shift unit in MiB = 2] [shifts = 40] [log2 of the virtual alignment; 0 = hipMalloc; -1 = offsets inside one hipMalloc; -2 = inside one physically contiguous allocation] [unit in bytes]
 // With an alignment the slab comes from the virtual-memory API: an address range reserved at that
 // alignment, one physical allocation mapped into it.
 #include <hip/hip_runtime.h>
@@ -56,7 +56,12 @@ int main(int argc, char** argv)
     if (align_log2 < 0) {
         // one allocation with room to spare: the arrays start `s` units into it
         char* slab = nullptr;
-        CK(hipMalloc((void**)&slab, arr * 12 + unit * (size_t)shifts));
+        if (align_log2 == -2) {   // physically contiguous
+            CK(hipExtMallocWithFlags((void**)&slab, arr * 12 + unit * (size_t)shifts, hipDeviceMallocContiguous));
+            printf("physically contiguous allocation at %p\n", (void*)slab);
+        } else {
+            CK(hipMalloc((void**)&slab, arr * 12 + unit * (size_t)shifts));
+        }
         for (int s = 0; s < shifts; ++s) {
             Arrays a;
             for (int k = 0; k < 6; ++k) {
