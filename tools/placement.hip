@@ -3,7 +3,7 @@
 // growing size and times the same capped copy (256-thread blocks, five per CU) on each.
 //
 //   hipcc --offload-arch=gfx950 -O3 -o tools/placement tools/placement.hip
-//   tools/placement [log2 n = 28] [shift unit in MiB = 2] [shifts = 40] [log2 of the virtual alignment; 0 = hipMalloc; -1 = offsets inside one hipMalloc; -2 = inside one physically contiguous allocation] [unit in bytes]
+//   tools/placement [log2 n = 28] [shift unit in MiB = 2] [shifts = 40] [log2 of the virtual alignment; 0 = hipMalloc; -1 = offsets inside one hipMalloc; -2 = inside one physically contiguous allocation; -3 = staggers between the arrays of a physically contiguous allocation] [unit in bytes]
 // With an alignment the slab comes from the virtual-memory API: an address range reserved at that
 // alignment, one physical allocation mapped into it.
 #include <hip/hip_runtime.h>
@@ -53,6 +53,36 @@ int main(int argc, char** argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
+    if (align_log2 == -3) {
+        // one physically contiguous allocation; the arrays 4n + 2 MiB + stagger apart, stagger = s * unit
+        const size_t stagger0 = argc > 6 ? (size_t)atol(argv[6]) : 0;   // first stagger of the sweep, bytes
+        const size_t max_arr = n * 4 + (2u << 20) + stagger0 + unit * (size_t)shifts;
+        char* slab = nullptr;
+        CK(hipExtMallocWithFlags((void**)&slab, max_arr * 12, hipDeviceMallocContiguous));
+        for (int s = 0; s < shifts; ++s) {
+            const size_t arr_s = n * 4 + (2u << 20) + stagger0 + unit * (size_t)s;
+            Arrays a;
+            for (int k = 0; k < 6; ++k) {
+                a.src[k] = reinterpret_cast<const f32x4*>(slab + (size_t)k * arr_s);
+                a.dst[k] = reinterpret_cast<f32x4*>(slab + (size_t)(6 + k) * arr_s);
+            }
+            a.n4 = n / 4;
+            float total = 0.f;
+            const int reps = 10;
+            for (int r = 0; r < reps + 1; ++r) {
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(deep_capped_kernel, dim3((unsigned)(a.n4 / 256)), dim3(256), 160 * 1024 / 5 - 1024, 0, a);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms = 0.f;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                if (r >= 1) total += ms;
+            }
+            printf("stagger %8zu B  avg %.4f ms  %.3f TB/s\n", stagger0 + unit * (size_t)s, total / reps, (double)n * 48.0 / (total / reps * 1e-3) / 1e12);
+            fflush(stdout);
+        }
+        return 0;
+    }
     if (align_log2 < 0) {
         // one allocation with room to spare: the arrays start `s` units into it
         char* slab = nullptr;
