@@ -87,6 +87,17 @@ class Pair:
     def op_reorder_now(self):
         self.dev.reorder_now()
 
+    def op_launch_shape(self):
+        """Block size and residency cap of the plain step (what large sets pick automatically), the packed
+        field copy on or off, plain or non-temporal loads: results never depend on them."""
+        block_sel, per_cu = int(self.rng.integers(4)), int(self.rng.choice([0, 1, 2, 5, 12, 15]))
+        variant = (block_sel << 28) | (per_cu << 24)
+        if self.rng.random() < 0.3:
+            variant |= 0x400000
+        if self.rng.random() < 0.3:
+            variant |= 0x1
+        self.dev.set_tuning(0, variant)
+
     def op_params(self):
         self.sp.masses = self.rng.uniform(0.2, 4.0, size=5).astype(np.float32)
         self.sp.max_velocity = np.float32(self.rng.choice([0.5, 20.0, 100.0]))
@@ -191,7 +202,7 @@ class Pair:
         if want["count"]:
             assert np.array_equal(d["pos_max"], want["pos_max"]) and np.array_equal(d["pos_min"], want["pos_min"]), self.log
 
-    OPS = (("step", 10), ("step_dt", 3), ("step_n", 4), ("interval", 4), ("reorder_now", 2), ("params", 2),
+    OPS = (("step", 10), ("step_dt", 3), ("step_n", 4), ("interval", 4), ("reorder_now", 2), ("launch_shape", 2), ("params", 2),
            ("pair_steps", 1), ("patch", 2), ("patch_indexed", 2), ("field_replace", 1), ("brush", 2), ("upload", 2),
            ("read_ranges", 2), ("pack", 1), ("diag", 2))
 
