@@ -46,7 +46,7 @@ def check(sizes, steps=18):
 if __name__ == "__main__":
     # usage: big_sizes_check.py [--steps K] log2n...
     argv = sys.argv[1:]
-    k = 14
+    k = 18
     if argv and argv[0] == "--steps":
         k = int(argv[1])
         argv = argv[2:]
