@@ -129,11 +129,14 @@ __global__ __launch_bounds__(kBlockThreads) void brush_select_kernel(
     }
 }
 
-// Cursor::mouse_moved: src/cursor.rs:79-103.
+// Cursor::mouse_moved: src/cursor.rs:79-103.  `field3` (may be null): the copy packed to 12 bytes per
+// cell, kept equal; `field_flag` (may be null): raised when a rewritten cell leaves the window of the
+// streaming kernels' packed path (cell_in_window).
 __global__ __launch_bounds__(kBlockThreads) void brush_apply_kernel(
     BrushInput by_value, const BrushInput* __restrict__ from_device, FieldGeometry G,
-    f32x4* __restrict__ field, float* __restrict__ field3, const BrushState* __restrict__ state,
-    const uint32_t* __restrict__ sel_index, const f32x4* __restrict__ sel_vector, uint32_t* error)
+    f32x4* __restrict__ field, float* __restrict__ field3, uint32_t* __restrict__ field_flag,
+    const BrushState* __restrict__ state, const uint32_t* __restrict__ sel_index,
+    const f32x4* __restrict__ sel_vector, uint32_t* error)
 {
     const BrushInput in = from_device ? *from_device : by_value;
     if (!brush_record_valid(in)) {
@@ -156,7 +159,8 @@ __global__ __launch_bounds__(kBlockThreads) void brush_apply_kernel(
         }
         out.w = 1.0f;                                                           // src/grid.rs:97-103
         field[c] = out;
-        if (field3) { field3[3u * c] = out.x; field3[3u * c + 1u] = out.y; field3[3u * c + 2u] = out.z; }   // the packed copy
+        if (field3) { field3[3ull * c] = out.x; field3[3ull * c + 1u] = out.y; field3[3ull * c + 2u] = out.z; }
+        if (field_flag && !cell_in_window(out.x, out.y, out.z)) atomicOr(field_flag, 1u);
     }
 }
 

@@ -24,6 +24,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 static_assert(sizeof(pcl_particle) == 48, "Particle is 48 bytes (src/main.rs:76-83)");
@@ -161,6 +162,11 @@ struct pcl_compute {
     float* field3 = nullptr;
     size_t field3_capacity = 0;
     bool field3_valid = false;
+    // device word the streaming kernels read: non-zero when some field component lies outside the window
+    // of their packed path (step_kernels.hpp: cell_in_window); recomputed over the whole field together
+    // with the packed copy, raised by the kernels that rewrite single cells
+    uint32_t* d_field_flag = nullptr;
+    bool field_checked = false;
     // field brush (src/cursor.rs): selection made by mouse_down, used by mouse_moved
     bool brush_down = false;
     pcl::BrushState* d_brush_state = nullptr;
@@ -287,6 +293,7 @@ int reserve_field(pcl_compute* h, size_t n_cells)
     h->field = nullptr;
     h->field_capacity = 0;
     h->field3_valid = false;
+    h->field_checked = false;
     PCL_HIP_TRY(hipMalloc((void**)&h->field, n_cells * sizeof(pcl::f32x4)));
     h->field_capacity = n_cells;
     return PCL_OK;
@@ -299,12 +306,13 @@ bool use_field3(const pcl_compute* h)
     return h->n_cells * sizeof(pcl::f32x4) > kAutoReorderMinFieldBytes && (h->variant & 0x400000u) == 0;
 }
 
-// Packed copy for the next streaming launch: null when not used, else brought up to date.
+// What a streaming launch needs beside the field itself: the packed copy (*out; null when not used)
+// and the window flag, both brought up to date with the field in one pass when either is stale.
 int current_field3(pcl_compute* h, const float** out)
 {
     *out = nullptr;
-    if (!use_field3(h)) return PCL_OK;
-    if (h->field3_capacity < h->n_cells) {
+    const bool packed = use_field3(h);
+    if (packed && h->field3_capacity < h->n_cells) {
         PCL_HIP_TRY(hipStreamSynchronize(h->stream));
         if (h->field3) (void)hipFree(h->field3);
         h->field3 = nullptr;
@@ -313,16 +321,28 @@ int current_field3(pcl_compute* h, const float** out)
         PCL_HIP_TRY(hipMalloc((void**)&h->field3, h->field_capacity * 3 * sizeof(float)));
         h->field3_capacity = h->field_capacity;
     }
-    if (!h->field3_valid) {
+    if (!h->field_checked || (packed && !h->field3_valid)) {
+        PCL_HIP_TRY(hipMemsetAsync(h->d_field_flag, 0, sizeof(uint32_t), h->stream));
         const size_t blocks = (h->n_cells + pcl::kBlockThreads - 1) / pcl::kBlockThreads;
-        hipLaunchKernelGGL(pcl::pack_field3_kernel, dim3((uint32_t)std::min<size_t>(blocks, 4096)), dim3(pcl::kBlockThreads), 0,
-                           h->stream, (const pcl::f32x4*)h->field, 0ull, (unsigned long long)h->n_cells, h->field3);
+        hipLaunchKernelGGL(pcl::prepare_field_kernel, dim3((uint32_t)std::min<size_t>(blocks, 4096)), dim3(pcl::kBlockThreads), 0,
+                           h->stream, (const pcl::f32x4*)h->field, 0ull, (unsigned long long)h->n_cells,
+                           packed ? h->field3 : (float*)nullptr, h->d_field_flag);
         PCL_HIP_TRY(hipGetLastError());
-        h->field3_valid = true;
+        h->field_checked = true;
+        if (packed) h->field3_valid = true;
     }
-    *out = h->field3;
+    if (packed) *out = h->field3;
     return PCL_OK;
 }
+
+// For the kernels that rewrite single cells: the packed copy and the flag to keep up to date, or
+// null while a full pass (current_field3) is pending anyway.
+float* live_field3(pcl_compute* h)
+{
+    if (!use_field3(h)) h->field3_valid = false;   // not kept while unused: a later use rebuilds it
+    return h->field3_valid ? h->field3 : nullptr;
+}
+uint32_t* live_field_flag(const pcl_compute* h) { return h->field_checked ? h->d_field_flag : nullptr; }
 
 int reserve_partials(pcl_compute* h, size_t blocks)
 {
@@ -365,6 +385,16 @@ pcl::StepUniforms uniforms_of(const pcl_compute* h)
     U.last_cell = (uint32_t)(h->n_cells - 1);
     U.degenerate = (U.neg_slh == U.slh) ? 1u : 0u;              // wgsl:69
     for (int k = 0; k < 5; ++k) U.mass[k] = p.particle_type_masses[k].mass;
+    // The packed path divides by these through their reciprocals (step_kernels.hpp: div_refined), which is
+    // exact while no intermediate leaves the normal range: divisors within [2^-40, 2^40] in magnitude.
+    auto in_window = [](float v) { const float a = std::fabs(v); return a >= 0x1p-40f && a <= 0x1p40f; };
+    bool ok = in_window(U.span_a) && in_window(U.slh) && (h->variant & 0x4u) == 0;   // tuning bit 4: scalar path only
+    U.rcp_span_a = ok ? (float)(1.0 / (double)U.span_a) : 0.0f;
+    for (int k = 0; k < 5; ++k) {
+        ok = ok && in_window(U.mass[k]);
+        U.rcp_mass[k] = in_window(U.mass[k]) ? (float)(1.0 / (double)U.mass[k]) : 0.0f;
+    }
+    U.fast_div = ok ? 1u : 0u;
     return U;
 }
 
@@ -478,16 +508,24 @@ size_t occupancy_pad(uint32_t cap, size_t used)
 }
 
 // More than 64 KiB of dynamic LDS (caps of one or two blocks per CU) has to be allowed per kernel
-// and per device, once.
+// and per device, once; remembered by the kernel's address (every instantiation is its own kernel).
+int allow_large_lds_impl(const void* kernel, int device, size_t bytes)
+{
+    if (bytes <= 64u * 1024u) return PCL_OK;
+    static std::mutex mutex;
+    static std::vector<std::pair<const void*, int>> done;
+    std::lock_guard<std::mutex> lock(mutex);
+    for (const auto& d : done)
+        if (d.first == kernel && d.second == device) return PCL_OK;
+    PCL_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    done.emplace_back(kernel, device);
+    return PCL_OK;
+}
+
 template <typename K>
 int allow_large_lds(K kernel, int device, size_t bytes)
 {
-    static bool done[64] = {};   // per kernel instantiation
-    if (bytes <= 64u * 1024u || device < 0 || device >= 64 || done[device]) return PCL_OK;
-    PCL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024 - 1024));
-    done[device] = true;
-    return PCL_OK;
+    return allow_large_lds_impl(reinterpret_cast<const void*>(kernel), device, bytes);
 }
 
 // Plain streaming step (field through the caches, no histogram) in blocks of BLOCK threads,
@@ -518,19 +556,36 @@ struct PlainShape {
     uint32_t cap;     // resident blocks per CU, 0 = as many as fit
 };
 
-constexpr size_t kCappedFromParticles = (size_t)3 << 24;   // 2^25: 0.3155 uncapped against 0.3165 ms capped; 1.5 * 2^25: 0.4548 against 0.4493
-
 // Tuning bits 24-27 = resident blocks per CU (15: no cap), bits 28-30 = block size (512 >> value);
 // all zero = automatic.  A caller-set grid cap (persistent blocks) keeps the one launch shape.
-PlainShape plain_shape(const pcl_compute* h, bool diag)
+//
+// Automatic: the update's arithmetic on the packed path (step_kernels.hpp: integrate2) is short enough for
+// the kernel to be fastest with few waves in flight; measured with 2^28 particles on a 1024^2 field:
+// 256 threads x 3 per CU (12 waves) 2.20 ms, x 2: 2.21, x 4: 2.34, x 5: 2.32; 128 x 4: 2.23; 512 x 2: 2.36;
+// 512 x 3 (what the registers allow): 2.36.  The same order from 2^20 particles up on that field (2^24: 0.147
+// against 0.169 ms uncapped) and from 2^23 up on a 256^2 field (2^22: 0.0424 capped against 0.0401).
+// With fused diagnostics (80 registers, a block-level fold at the end) four blocks: 2^27 particles
+// 1.155 ms against 1.209 uncapped and 1.338 at three.  On the scalar path (operands outside the packed
+// path's window) the arithmetic is twice as long and five blocks were the optimum (2.28 against 2.34 ms).
+PlainShape plain_shape(const pcl_compute* h, bool diag, bool packed)
 {
     const uint32_t cap_bits = (h->variant >> 24) & 0xFu, bsel = (h->variant >> 28) & 7u;
     if (cap_bits || bsel) return PlainShape{512u >> std::min(bsel, 3u), cap_bits > 12u ? 0u : cap_bits};
-    // measured at 2^28 particles, 1024^2 field: 2.28 ms against 2.34 ms with the three 512-thread blocks
-    // per CU that 70 registers allow (512 x 2: 2.28; 256 x 4: 2.33; 256 x 6: 2.31; 256 x 7: 2.33);
-    // 2^26: 0.582 against 0.592 ms; with fused diagnostics (80 registers) a cap only costs
-    if (!diag && h->n >= kCappedFromParticles) return PlainShape{256u, 5u};
-    return PlainShape{(uint32_t)pcl::kStreamThreads, 0u};
+    const size_t field_bytes = h->n_cells * sizeof(pcl::f32x4);
+    const bool large = h->n >= ((size_t)1 << 23) || (h->n >= ((size_t)1 << 20) && field_bytes > ((size_t)4 << 20));
+    if (!large) return PlainShape{(uint32_t)pcl::kStreamThreads, 0u};
+    if (!packed) return (diag || h->n < ((size_t)3 << 24)) ? PlainShape{(uint32_t)pcl::kStreamThreads, 0u} : PlainShape{256u, 5u};
+    return PlainShape{256u, diag ? 4u : 3u};
+}
+
+// Resident blocks per CU of the counting step (512 threads; 0: whatever fits).  2^28 particles: 2.46 ms at
+// three (2.46 at two) against 2.65 ms without the cap, although the registers allow three either way;
+// with fused diagnostics the cap costs (2^27: 1.44 against 1.33 ms).  Tuning bits 20-21 override.
+uint32_t count_cap(const pcl_compute* h, bool diag, bool packed)
+{
+    const uint32_t bits = (h->variant >> 20) & 3u;
+    if (bits) return bits;
+    return (packed && !diag && h->n >= ((size_t)1 << 22)) ? 3u : 0u;
 }
 
 template <bool DIAG, bool NT>
@@ -538,7 +593,7 @@ int launch_stream(pcl_compute* h, const pcl::StreamArgs& a, const pcl::StepUnifo
                   uint32_t& grid, bool lds, bool count)
 {
     if (!lds && !count && !h->grid_cap) {
-        const PlainShape shape = plain_shape(h, DIAG);
+        const PlainShape shape = plain_shape(h, DIAG, U.fast_div != 0u);
         if (shape.cap || shape.block != (uint32_t)pcl::kStreamThreads) {
             switch (shape.block) {
             case 512: return launch_plain_shaped<DIAG, NT, 512>(h, a, U, T, shape.cap, grid);
@@ -553,7 +608,8 @@ int launch_stream(pcl_compute* h, const pcl::StreamArgs& a, const pcl::StepUnifo
         hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, true, false>), dim3(grid),
                            dim3(pcl::kStreamThreads), bytes, h->stream, a, U, T);
     } else if (count) {
-        const size_t bytes = (size_t)T.n_bins * sizeof(uint32_t);
+        const size_t bytes = occupancy_pad(count_cap(h, DIAG, U.fast_div != 0u), (size_t)T.n_bins * sizeof(uint32_t));
+        if (int rc = allow_large_lds(pcl::step_stream_kernel<DIAG, NT, false, true>, h->device, bytes)) return rc;
         hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, false, true>), dim3(grid),
                            dim3(pcl::kStreamThreads), bytes, h->stream, a, U, T);
     } else {
@@ -797,11 +853,12 @@ void reorder_commit(pcl_compute* h)
 
 // One counting-sort pass state[cur] -> state[cur ^ 1] by field tile of the
 // current positions (no time step).
-int do_reorder(pcl_compute* h)
+// `aim`: which point of the refresh interval the keys look at (see make_tile_map); negative = backwards.
+int do_reorder(pcl_compute* h, float aim)
 {
     if (h->n == 0) return PCL_OK;
     if (int rc = reserve_reorder(h)) return rc;
-    const pcl::TileMap T = make_tile_map(h->params, effective_reorder_interval(h), tile_log2(h), tile_aim(h));
+    const pcl::TileMap T = make_tile_map(h->params, effective_reorder_interval(h), tile_log2(h), aim);
     const pcl::StepUniforms U = uniforms_of(h);
     if (int rc = reorder_count(h, U, T, pcl::kCursorGroups)) return rc;
     pcl::ReorderArgs a;
@@ -948,6 +1005,14 @@ int do_step_impl(pcl_compute* h, int* kind)
         // which the scatter kernel must detect and report through the error word
         if (sort_now && h->hist_valid && (h->variant & 0x40000u)) T.lookahead += 1.0f;
         if (sort_now) {
+            // Particles in caller order (fresh upload) are sorted twice: first by the tile they were in half an
+            // interval AGO, then, below, like every refresh, by the tile they will be in half an interval from
+            // now.  A refresh appends each source tile's particles to their new tile in source order, so from
+            // the second refresh on the particles of one tile are sub-ordered by where they came from, i.e. by
+            // velocity, and neighbours in memory stay neighbours in the field for the whole interval; the extra
+            // pass gives the first interval after an upload that same quality (tuning bit 0x200 skips it).
+            if (!h->sorted && interval > 1 && (h->variant & 0x200u) == 0)
+                if (int rc = do_reorder(h, -tile_aim(h))) return rc;
             // Update and scatter into tile order in one pass.
             if (int rc = reserve_reorder(h)) return rc;
             if (!h->hist_valid)
@@ -960,6 +1025,7 @@ int do_step_impl(pcl_compute* h, int* kind)
             const float* packed = nullptr;
             if (int rc = current_field3(h, &packed)) return rc;
             sa.field3 = packed;
+            sa.field_flag = h->d_field_flag;
             sa.partials = h->d_partials;
             const size_t lds_bytes = pcl::scatter_lds_bytes(T.n_bins);
             if (h->step_diag)
@@ -1014,6 +1080,7 @@ int do_step_impl(pcl_compute* h, int* kind)
             const float* packed = nullptr;
             if (int rc = current_field3(h, &packed)) return rc;
             a.field3 = packed;
+            a.field_flag = h->d_field_flag;
             a.runs = (count && !h->runs_pending) ? h->d_runs : nullptr;
             const bool lds = use_lds_field(h);
             a.lds_cells = lds ? (uint32_t)h->n_cells : 0u;
@@ -1215,6 +1282,7 @@ int upload_field(pcl_compute* h, size_t first_cell, const void* src, size_t coun
 {
     if (count == 0) return PCL_OK;
     h->field3_valid = false;
+    h->field_checked = false;
     PCL_HIP_TRY(hipMemcpyAsync(h->field + first_cell, src, count * sizeof(pcl::f32x4),
                                from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                                h->stream));
@@ -1288,8 +1356,8 @@ int brush_mouse_moved(pcl_compute* h, const pcl_brush_input* host_in, const void
     const uint32_t grid = std::min<uint32_t>(linear_grid(h, h->n_cells), 1024u);
     hipLaunchKernelGGL(pcl::brush_apply_kernel, dim3(grid), dim3(pcl::kBlockThreads), 0, h->stream,
                        brush_input_of(host_in), static_cast<const pcl::BrushInput*>(dev_in), G, h->field,
-                       h->field3_valid ? h->field3 : nullptr, (const pcl::BrushState*)h->d_brush_state, (const uint32_t*)h->d_brush_index,
-                       (const pcl::f32x4*)h->d_brush_vector, h->d_error);
+                       live_field3(h), live_field_flag(h), (const pcl::BrushState*)h->d_brush_state,
+                       (const uint32_t*)h->d_brush_index, (const pcl::f32x4*)h->d_brush_vector, h->d_error);
     PCL_HIP_TRY(hipGetLastError());
     return PCL_OK;
 }
@@ -1305,6 +1373,7 @@ hipStream_t stream_of(const pcl_compute* h) { return h->stream; }
 void* field_of(pcl_compute* h)
 {
     h->field3_valid = false;   // handed out for writing (collectives deliver cells straight into it)
+    h->field_checked = false;
     return h->field;
 }
 size_t cells_of(const pcl_compute* h) { return h->n_cells; }
@@ -1321,6 +1390,7 @@ int field_for_write(pcl_compute* h, size_t n_cells, void** dev_field)
     if (n_cells != h->n_cells) h->brush_down = false;   // a selection indexes the field it was made on
     h->n_cells = n_cells;
     h->field3_valid = false;   // the caller is about to write the cells
+    h->field_checked = false;
     *dev_field = h->field;
     return PCL_OK;
 }
@@ -1379,6 +1449,7 @@ int pcl_destroy(pcl_compute* h)
     if (h->d_sort_temp) (void)hipFree(h->d_sort_temp);
     if (h->d_bin_end) (void)hipFree(h->d_bin_end);
     if (h->d_error) (void)hipFree(h->d_error);
+    if (h->d_field_flag) (void)hipFree(h->d_field_flag);
     if (h->h_error) (void)hipHostFree(h->h_error);
     if (h->h_runs) (void)hipHostFree(h->h_runs);
     if (h->ev_runs) (void)hipEventDestroy(h->ev_runs);
@@ -1441,6 +1512,7 @@ int pcl_create(const pcl_particle* particles, size_t n, const float (*force_grid
     PCL_CREATE_TRY(hipEventCreate(&h->ev_stop));
     PCL_CREATE_TRY(hipMalloc((void**)&h->d_params, sizeof(pcl_sim_params)));
     PCL_CREATE_TRY(hipMalloc((void**)&h->d_diag, sizeof(pcl::DiagOut)));
+    PCL_CREATE_TRY(hipMalloc((void**)&h->d_field_flag, sizeof(uint32_t)));
     PCL_CREATE_TRY(hipMalloc((void**)&h->d_error, sizeof(uint32_t)));
     PCL_CREATE_TRY(hipMemset(h->d_error, 0, sizeof(uint32_t)));
     PCL_CREATE_TRY(hipHostMalloc((void**)&h->h_error, sizeof(uint32_t), hipHostMallocDefault));
@@ -1590,7 +1662,7 @@ int pcl_patch_force_grid_indexed(pcl_compute* h, const uint32_t* cell_indices, c
     if (e == hipSuccess) e = hipMemcpyAsync(d_index, cell_indices, count * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(pcl::patch_field_kernel, dim3(linear_grid(h, count)), dim3(pcl::kBlockThreads), 0, h->stream,
-                           h->field, h->field3_valid ? h->field3 : nullptr, (unsigned long long)h->n_cells,
+                           h->field, live_field3(h), live_field_flag(h), (unsigned long long)h->n_cells,
                            (const uint32_t*)d_index, (const pcl::f32x4*)d_cells, (unsigned long long)count);
         e = hipGetLastError();
     }
@@ -1606,7 +1678,7 @@ int pcl_patch_force_grid_indexed_device(pcl_compute* h, const void* dev_cell_ind
     if (count == 0) return PCL_OK;
     PCL_REQUIRE(dev_cell_indices != nullptr && dev_cells != nullptr, "pcl_patch_force_grid_indexed_device: null argument");
     hipLaunchKernelGGL(pcl::patch_field_kernel, dim3(linear_grid(h, count)), dim3(pcl::kBlockThreads), 0, h->stream,
-                       h->field, h->field3_valid ? h->field3 : nullptr, (unsigned long long)h->n_cells,
+                       h->field, live_field3(h), live_field_flag(h), (unsigned long long)h->n_cells,
                        reinterpret_cast<const uint32_t*>(dev_cell_indices), reinterpret_cast<const pcl::f32x4*>(dev_cells),
                        (unsigned long long)count);
     PCL_HIP_TRY(hipGetLastError());
@@ -2038,7 +2110,7 @@ int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks, uint32_t* b
     if (!h) return fail(PCL_ERR_INVALID, "null handle");
     uint32_t blocks = stream_grid(h), threads = pcl::kStreamThreads;
     if (!use_lds_field(h) && !h->grid_cap) {   // the plain step's own shape (the counting and scatter steps keep 512 threads)
-        const PlainShape shape = plain_shape(h, h->step_diag);
+        const PlainShape shape = plain_shape(h, h->step_diag, uniforms_of(h).fast_div != 0u);
         threads = shape.block;
         blocks = (uint32_t)std::min<size_t>(std::max<size_t>(1, (h->n / 4 + threads - 1) / threads), 0x7FFFFFFFu);
     }
@@ -2063,10 +2135,28 @@ int pcl_reorder_now(pcl_compute* h)
 {
     if (int rc = bind(h)) return rc;
     PCL_REQUIRE(h->n < 0xFFFFFFFFull, "pcl_reorder_now: more than 2^32 - 2 particles");
-    return do_reorder(h);
+    return do_reorder(h, tile_aim(h));
 }
 
 uint64_t pcl_reorder_count(const pcl_compute* h) { return h ? h->reorders : 0; }
+
+#ifdef PCL_PHASE_CLOCKS
+int pcl_debug_experiment(pcl_compute* h, int mode)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+    PCL_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pcl::experiment_mode), &mode, sizeof mode));
+    return PCL_OK;
+}
+// development builds only: the phase clocks of the last scatter launch (256 sampled blocks x 24 stamps)
+int pcl_debug_phase_clocks(pcl_compute* h, unsigned long long* out)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_HIP_TRY(hipStreamSynchronize(h->stream));
+    PCL_HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(pcl::phase_clocks), sizeof(unsigned long long) * 256 * 24));
+    return PCL_OK;
+}
+#endif
 
 int pcl_set_tuning(pcl_compute* h, uint32_t grid_blocks, uint32_t variant)
 {

@@ -44,6 +44,12 @@ struct StepUniforms {
     uint32_t last_cell;  // n_cells - 1: index clamp for the fetch
     uint32_t degenerate; // start_a == end_a                           wgsl:69
     float mass[5];       // particle_type_masses[k].mass               wgsl:109
+    // Operands of the refined-reciprocal divisions (integrate4): correctly rounded reciprocals,
+    // evaluated on the host, of the launch-uniform divisors; fast_div says that all of them lie in
+    // the exponent window in which those divisions are exact (uniforms_of in particles_hip.hip).
+    float rcp_span_a;
+    float rcp_mass[5];
+    uint32_t fast_div;
 };
 
 struct DiagPartial {
@@ -133,6 +139,190 @@ __device__ __forceinline__ void integrate(const StepUniforms& U, float fx, float
     x = wrap_symmetrically(x, U.radius, U.two_radius);
     y = wrap_symmetrically(y, U.radius, U.two_radius);
     z = wrap_symmetrically(z, U.radius, U.two_radius);
+}
+
+// ------------------------------------------------ packed fast path (4 particles per lane)
+//
+// The same update, the same correctly rounded results, in about two thirds of the vector
+// instructions:
+//  * two particles per instruction through the packed fp32 operations of CDNA (v_pk_mul_f32,
+//    v_pk_add_f32, v_pk_fma_f32): a lane holds 4 consecutive particles per array, i.e. two
+//    register pairs;
+//  * a / b for the six divisions per particle whose divisor is uniform over the launch (the span
+//    of the bounding volume, wgsl:75; the five masses, wgsl:148) as the refinement steps of the
+//    hardware's own division sequence
+//        q0 = a * y,  r0 = fma(-b, q0, a),  q1 = fma(r0, y, q0),  r1 = fma(-b, q1, a),  q = fma(r1, y, q1)
+//    on the divisor's correctly rounded reciprocal y, which the host evaluates once.  What the full
+//    sequence adds, scaling of operands with extreme exponents and the fix-up of zeros, infinities
+//    and NaNs, is replaced by preconditions under which no intermediate overflows, underflows or
+//    loses a bit: divisors within [2^-40, 2^40] in magnitude (checked on the host: fast_div), field
+//    components zero or within [2^-60, 2^60] (checked by the kernels that write the field: a device
+//    flag, cell_in_window); a launch whose operands are outside takes the scalar path, kernel by
+//    kernel.  tools/debug/divcheck.c holds the host-side check of the sequence (every significand
+//    against 48 divisors, 2 * 10^9 random pairs inside the window: no mismatch);
+//  * sqrt as v_sqrt_f32 and the hardware lowering's one-ulp correction without its scaling of
+//    arguments below 2^-96: the root of such an argument is far below the 0.001 threshold of
+//    wgsl:157, above which alone the value of the root is used.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+
+__device__ __forceinline__ f32x2 div_refined(f32x2 a, f32x2 neg_b, f32x2 y)
+{
+    f32x2 q = a * y;
+    f32x2 r = fma2(neg_b, q, a);
+    q = fma2(r, y, q);
+    r = fma2(neg_b, q, a);
+    return fma2(r, y, q);
+}
+
+// Correctly rounded square root for arguments that are +0, +inf or at least 2^-96; anything
+// below 2^-96 yields a value below 2^-47.
+__device__ __forceinline__ float sqrt_no_scaling(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+    const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x);
+    const float r_up = __builtin_fmaf(-s_up, s, x);
+    float r = r_dn <= 0.0f ? s_dn : s;
+    r = r_up > 0.0f ? s_up : r;
+    return r;
+}
+
+// wgsl:81-89 for two particles; not for the degenerate range (start_a == end_a).
+__device__ __forceinline__ void cell_index2(const StepUniforms& U, f32x2 x, f32x2 y, f32x2 z, uint32_t out[2])
+{
+    const f32x2 neg_span = splat2(-U.span_a), rcp = splat2(U.rcp_span_a), lo = splat2(U.neg_slh);
+    auto axis = [&](f32x2 v, float span_b) -> f32x2 {
+        f32x2 c;
+        c.x = fminf(fmaxf(v.x, U.neg_slh), U.slh);
+        c.y = fminf(fmaxf(v.y, U.neg_slh), U.slh);
+        // oz * span_b (the shader's "+ start_b" adds +0 to a value that is never negative)
+        return div_refined(c - lo, neg_span, rcp) * splat2(span_b);
+    };
+    const f32x2 fx = axis(x, U.span_b[0]), fy = axis(y, U.span_b[1]), fz = axis(z, U.span_b[2]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t fgi = (uint32_t)fx[k] * U.dim_y * U.dim_z + (uint32_t)fy[k] * U.dim_z + (uint32_t)fz[k];
+        out[k] = fgi < U.last_cell ? fgi : U.last_cell;
+    }
+}
+
+// wgsl:148-172 for two particles (fx, fy, fz: their field cells; m, rm: their masses and the
+// masses' reciprocals); pair acceleration zero.
+__device__ __forceinline__ void integrate2(const StepUniforms& U, f32x2 fx, f32x2 fy, f32x2 fz, f32x2 m, f32x2 rm,
+                                           f32x2& x, f32x2& y, f32x2& z, f32x2& vx, f32x2& vy, f32x2& vz)
+{
+    const f32x2 ten = splat2(10.0f), zero = splat2(0.0f), neg_m = -m;
+    const f32x2 ax = zero + div_refined(ten * fx, neg_m, rm);
+    const f32x2 ay = zero + div_refined(ten * fy, neg_m, rm);
+    const f32x2 az = zero + div_refined(ten * fz, neg_m, rm);
+    const f32x2 decay = splat2(U.decay), dt = splat2(U.dt);
+    f32x2 wx = vx * decay + ax * dt;
+    f32x2 wy = vy * decay + ay * dt;
+    f32x2 wz = vz * decay + az * dt;
+
+    const f32x2 s = (wx * wx + wy * wy) + wz * wz;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float vel = sqrt_no_scaling(s[k]);
+        const float capped = fminf(fmaxf(vel, 0.0f), U.max_velocity);
+        const bool moving = vel > 0.001f;
+        // The three divisions by the particle's own speed keep the full sequence: nothing bounds their
+        // operands in advance (a refined variant with a per-particle window test and fall-back measured
+        // slower: the test and the branch cost more than the seven instructions per division they save).
+        const float nx = __fdiv_rn(wx[k], vel) * capped;
+        const float ny = __fdiv_rn(wy[k], vel) * capped;
+        const float nz = __fdiv_rn(wz[k], vel) * capped;
+        wx[k] = moving ? nx : wx[k];
+        wy[k] = moving ? ny : wy[k];
+        wz[k] = moving ? nz : wz[k];
+    }
+    vx = wx; vy = wy; vz = wz;
+    x = x + vx * dt;
+    y = y + vy * dt;
+    z = z + vz * dt;
+    const f32x2 two_r = splat2(U.two_radius);
+    auto wrap = [&](f32x2& p) {
+        const f32x2 down = p - two_r, up = p + two_r;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float low = p[k] < -U.radius ? up[k] : p[k];
+            p[k] = p[k] > U.radius ? down[k] : low;
+        }
+    };
+    wrap(x); wrap(y); wrap(z);
+}
+
+// Masses and their reciprocals by particle type, one private copy per wave in LDS (a table
+// look-up instead of a chain of selects per particle); types above 4 read the last mass, as
+// mass_of does.  A wave's own LDS writes and reads execute in order, so no barrier is needed.
+struct MassTable {
+    float2* tab;   // this wave's 8 entries
+    __device__ __forceinline__ void init(float2* wave_tab, const StepUniforms& U)
+    {
+        tab = wave_tab;
+        // one lane writes all eight entries from the scalar registers the masses arrive in (an index
+        // computed per lane would turn into a load from the kernel-argument block)
+        if ((threadIdx.x & 63u) == 0u) {
+            wave_tab[0] = make_float2(U.mass[0], U.rcp_mass[0]);
+            wave_tab[1] = make_float2(U.mass[1], U.rcp_mass[1]);
+            wave_tab[2] = make_float2(U.mass[2], U.rcp_mass[2]);
+            wave_tab[3] = make_float2(U.mass[3], U.rcp_mass[3]);
+            const float2 last = make_float2(U.mass[4], U.rcp_mass[4]);
+            wave_tab[4] = last; wave_tab[5] = last; wave_tab[6] = last; wave_tab[7] = last;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    }
+    __device__ __forceinline__ float2 of(uint32_t ty) const { return tab[ty < 7u ? ty : 7u]; }
+};
+
+// One update of a lane's 4 consecutive particles on the packed path (cell_index2, integrate2);
+// `fetch(cell)` returns the field value, m[] receives the particles' masses.
+template <typename Fetch>
+__device__ __forceinline__ void step4_packed(const StepUniforms& U, const MassTable& M, uint32_t t4, Fetch fetch,
+                                             f32x4& X, f32x4& Y, f32x4& Z, f32x4& VX, f32x4& VY, f32x4& VZ, float m[4])
+{
+    uint32_t ci[4];
+    cell_index2(U, X.xy, Y.xy, Z.xy, ci);
+    cell_index2(U, X.zw, Y.zw, Z.zw, ci + 2);
+    f32x4 F[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) F[k] = fetch(ci[k]);
+    float2 mt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mt[k] = M.of((t4 >> (8 * k)) & 0xFFu); m[k] = mt[k].x; }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int a = 2 * h, b = 2 * h + 1;
+        f32x2 x = {X[a], X[b]}, y = {Y[a], Y[b]}, z = {Z[a], Z[b]};
+        f32x2 vx = {VX[a], VX[b]}, vy = {VY[a], VY[b]}, vz = {VZ[a], VZ[b]};
+        integrate2(U, f32x2{F[a].x, F[b].x}, f32x2{F[a].y, F[b].y}, f32x2{F[a].z, F[b].z},
+                   f32x2{mt[a].x, mt[b].x}, f32x2{mt[a].y, mt[b].y}, x, y, z, vx, vy, vz);
+        X[a] = x.x; X[b] = x.y; Y[a] = y.x; Y[b] = y.y; Z[a] = z.x; Z[b] = z.y;
+        VX[a] = vx.x; VX[b] = vx.y; VY[a] = vy.x; VY[b] = vy.y; VZ[a] = vz.x; VZ[b] = vz.y;
+    }
+}
+
+// The scalar path for a lane's four particles (full divisions, the library square root).
+template <typename Fetch>
+__device__ __forceinline__ void step4_scalar(const StepUniforms& U, uint32_t t4, Fetch fetch,
+                                             f32x4& X, f32x4& Y, f32x4& Z, f32x4& VX, f32x4& VY, f32x4& VZ, float m[4])
+{
+    f32x4 F[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) F[k] = fetch(cell_index(U, X[k], Y[k], Z[k]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        m[k] = mass_of(U, (t4 >> (8 * k)) & 0xFFu);
+        float x = X[k], y = Y[k], z = Z[k], vx = VX[k], vy = VY[k], vz = VZ[k];
+        integrate(U, F[k].x, F[k].y, F[k].z, m[k], 0.0f, 0.0f, 0.0f, x, y, z, vx, vy, vz);
+        X[k] = x; Y[k] = y; Z[k] = z; VX[k] = vx; VY[k] = vy; VZ[k] = vz;
+    }
 }
 
 // Barrier for hand-offs that go through LDS only.  __syncthreads() also waits
@@ -326,13 +516,15 @@ struct Cell3 {
     float x, y, z;
 };
 
+// One launch-uniform choice of copy, made without a branch (a branch per fetch would end a basic
+// block at every fetch and keep the four fetches of a lane from being in flight together): both
+// copies are read as 12 bytes at cell * stride.
 __device__ __forceinline__ f32x4 fetch_cell(const f32x4* __restrict__ field, const float* __restrict__ field3, uint32_t c)
 {
-    if (field3) {
-        const Cell3 v = reinterpret_cast<const Cell3*>(field3)[c];
-        return f32x4{v.x, v.y, v.z, 1.0f};
-    }
-    return field[c];
+    const char* base = field3 ? reinterpret_cast<const char*>(field3) : reinterpret_cast<const char*>(field);
+    const uint32_t stride = field3 ? 12u : 16u;
+    const Cell3 v = *reinterpret_cast<const Cell3*>(base + (unsigned long long)c * stride);
+    return f32x4{v.x, v.y, v.z, 1.0f};
 }
 
 struct StreamArgs {
@@ -347,7 +539,18 @@ struct StreamArgs {
     uint32_t hist_groups;
     uint32_t* runs;         // when COUNT: total over blocks of the bins each block touched (may be null)
     const float* __restrict__ field3;   // the field packed to 12 bytes per cell, or null (fetch_cell)
+    const uint32_t* __restrict__ field_flag;   // non-zero: some field component is outside the packed path's window
 };
+
+// Whether this launch may take the packed path: the host's verdict on the uniform divisors and
+// the device flag that the kernels writing the field keep.  Uniform over the launch.
+__device__ __forceinline__ bool packed_path_ok(const StepUniforms& U, const uint32_t* field_flag)
+{
+#ifdef PCL_FORCE_PACKED   // analysis builds: the packed path alone
+    return true;
+#endif
+    return U.fast_div != 0u && U.degenerate == 0u && field_flag != nullptr && *field_flag == 0u;
+}
 
 template <bool NT>
 __device__ __forceinline__ f32x4 load4(const float* base, unsigned long long group)
@@ -401,32 +604,16 @@ constexpr int kStreamThreads = PCL_STREAM_THREADS;
 constexpr int kStreamTile = kStreamThreads * kParticlesPerLane;
 constexpr uint32_t kRunSlots = 256;   // counters of StreamArgs::runs
 
-// COUNT: also histogram the field tile of every OUTPUT position into a.hist
-// (LDS counters per persistent block, one global atomic per non-empty bin), so
-// that the next step can be a step_scatter_kernel without a counting pass.
-// FIELD_LDS and COUNT are exclusive (both use the dynamic LDS).
-// The counting variant with fused diagnostics is held to the 80 registers that three resident blocks allow.
-template <bool DIAG, bool NT, bool FIELD_LDS, bool COUNT = false, int BLOCK = kStreamThreads>
-__global__ __launch_bounds__(BLOCK, (DIAG && COUNT) ? 6 : 1) void step_stream_kernel(StreamArgs a, StepUniforms U, TileMap T)
+// The tiles of one block (and, in block 0, the up to 3 particles past the last full group), either
+// on the packed path (PACKED; see integrate2) or on the scalar one.  The two are separate
+// instantiations so that neither's registers weigh on the other; the kernel picks one per launch.
+template <bool DIAG, bool NT, bool FIELD_LDS, bool COUNT, int BLOCK, bool PACKED>
+__device__ __forceinline__ void stream_tiles(const StreamArgs& a, const StepUniforms& U, const TileMap& T,
+                                             const f32x4* lds_field, uint32_t* lds_hist, float2* wave_mass_tab, DiagAcc& acc)
 {
-    // Small fields (<= 64 KiB; the host decides when it pays) are staged in LDS once per persistent block;
-    // larger ones are fetched through L2 / Infinity Cache.
-    extern __shared__ __attribute__((aligned(16))) f32x4 lds_field[];
-    uint32_t* lds_hist = reinterpret_cast<uint32_t*>(lds_field);
-    if (FIELD_LDS) {
-        for (uint32_t c = threadIdx.x; c < a.lds_cells; c += BLOCK) lds_field[c] = a.field[c];
-        __syncthreads();
-    }
-    __shared__ uint32_t touched_sh;
-    if (COUNT) {
-        for (uint32_t b = threadIdx.x; b < T.n_bins; b += BLOCK) lds_hist[b] = 0u;
-        if (threadIdx.x == 0) touched_sh = 0u;
-        __syncthreads();
-    }
     auto fetch = [&](uint32_t c) -> f32x4 { return FIELD_LDS ? lds_field[c] : fetch_cell(a.field, a.field3, c); };
-
-    DiagAcc acc;
-    if (DIAG) acc.init();
+    MassTable M;
+    if (PACKED) M.init(wave_mass_tab, U);
 
     const unsigned long long n_groups = a.n / 4ull;
     const unsigned long long n_tiles = (n_groups + BLOCK - 1) / BLOCK;
@@ -457,18 +644,13 @@ __global__ __launch_bounds__(BLOCK, (DIAG && COUNT) ? 6 : 1) void step_stream_ke
             t4 = reinterpret_cast<const uint32_t*>(a.ty)[g];
         }
 
-        f32x4 F[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) F[k] = fetch(cell_index(U, X[k], Y[k], Z[k]));
-
+        float m[4];
+        if (PACKED) step4_packed(U, M, t4, fetch, X, Y, Z, VX, VY, VZ, m);
+        else step4_scalar(U, t4, fetch, X, Y, Z, VX, VY, VZ, m);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float m = mass_of(U, (t4 >> (8 * k)) & 0xFFu);
-            float x = X[k], y = Y[k], z = Z[k], vx = VX[k], vy = VY[k], vz = VZ[k];
-            integrate(U, F[k].x, F[k].y, F[k].z, m, 0.0f, 0.0f, 0.0f, x, y, z, vx, vy, vz);
-            X[k] = x; Y[k] = y; Z[k] = z; VX[k] = vx; VY[k] = vy; VZ[k] = vz;
-            if (DIAG) acc.add(m, x, y, z, vx, vy, vz);
-            if (COUNT) lds_rank_add(lds_hist, tile_key(U, T, x, y, z, vx, vy, vz), true);
+            if (DIAG) acc.add(m[k], X[k], Y[k], Z[k], VX[k], VY[k], VZ[k]);
+            if (COUNT) lds_rank_add(lds_hist, tile_key(U, T, X[k], Y[k], Z[k], VX[k], VY[k], VZ[k]), true);
         }
 
         if (NT) {
@@ -488,7 +670,7 @@ __global__ __launch_bounds__(BLOCK, (DIAG && COUNT) ? 6 : 1) void step_stream_ke
         }
     }
 
-    // Up to 3 particles past the last full group: block 0, lanes 0..2.
+    // Up to 3 particles past the last full group: block 0, lanes 0..2 (scalar path: identical results).
     const unsigned long long tail = n_groups * 4ull + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < 3 && tail < a.n) {
         float x = a.src[0][tail], y = a.src[1][tail], z = a.src[2][tail];
@@ -501,6 +683,39 @@ __global__ __launch_bounds__(BLOCK, (DIAG && COUNT) ? 6 : 1) void step_stream_ke
         if (DIAG) acc.add(m, x, y, z, vx, vy, vz);
         if (COUNT) atomicAdd(&lds_hist[tile_key(U, T, x, y, z, vx, vy, vz)], 1u);
     }
+}
+
+// COUNT: also histogram the field tile of every OUTPUT position into a.hist
+// (LDS counters per persistent block, one global atomic per non-empty bin), so
+// that the next step can be a step_scatter_kernel without a counting pass.
+// FIELD_LDS and COUNT are exclusive (both use the dynamic LDS).
+// The counting variant with fused diagnostics is held to the 80 registers that three resident blocks allow.
+template <bool DIAG, bool NT, bool FIELD_LDS, bool COUNT = false, int BLOCK = kStreamThreads>
+__global__ __launch_bounds__(BLOCK, (DIAG && COUNT) ? 6 : 1) void step_stream_kernel(StreamArgs a, StepUniforms U, TileMap T)
+{
+    // Small fields (<= 64 KiB; the host decides when it pays) are staged in LDS once per persistent block;
+    // larger ones are fetched through L2 / Infinity Cache.
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds_field[];
+    uint32_t* lds_hist = reinterpret_cast<uint32_t*>(lds_field);
+    if (FIELD_LDS) {
+        for (uint32_t c = threadIdx.x; c < a.lds_cells; c += BLOCK) lds_field[c] = a.field[c];
+        __syncthreads();
+    }
+    __shared__ uint32_t touched_sh;
+    if (COUNT) {
+        for (uint32_t b = threadIdx.x; b < T.n_bins; b += BLOCK) lds_hist[b] = 0u;
+        if (threadIdx.x == 0) touched_sh = 0u;
+        __syncthreads();
+    }
+    __shared__ float2 mass_tab[BLOCK / 64][8];
+
+    DiagAcc acc;
+    if (DIAG) acc.init();
+
+    if (packed_path_ok(U, a.field_flag))
+        stream_tiles<DIAG, NT, FIELD_LDS, COUNT, BLOCK, true>(a, U, T, lds_field, lds_hist, mass_tab[threadIdx.x >> 6], acc);
+    else
+        stream_tiles<DIAG, NT, FIELD_LDS, COUNT, BLOCK, false>(a, U, T, lds_field, lds_hist, mass_tab[threadIdx.x >> 6], acc);
 
     if (COUNT) {
         lds_barrier();   // LDS counters only: no need to drain the stores first
@@ -534,6 +749,10 @@ template <bool DIAG>
 __global__ __launch_bounds__(kStreamThreads) void step_stream_fused_kernel(StreamArgs a, StepUniforms U,
                                                                           uint32_t sub_steps)
 {
+    __shared__ float2 mass_tab[kStreamThreads / 64][8];
+    const bool packed = packed_path_ok(U, a.field_flag);
+    MassTable M;
+    if (packed) M.init(mass_tab[threadIdx.x >> 6], U);
     DiagAcc acc;
     if (DIAG) acc.init();
     const unsigned long long n_groups = a.n / 4ull;
@@ -552,6 +771,10 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_fused_kernel(Strea
         float m[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) m[k] = mass_of(U, (t4 >> (8 * k)) & 0xFFu);
+        if (packed) {
+            auto fetch = [&](uint32_t c) -> f32x4 { return fetch_cell(a.field, a.field3, c); };
+            for (uint32_t s = 0; s < sub_steps; ++s) step4_packed(U, M, t4, fetch, X, Y, Z, VX, VY, VZ, m);
+        } else {
         for (uint32_t s = 0; s < sub_steps; ++s) {
             f32x4 F[4];
 #pragma unroll
@@ -562,6 +785,7 @@ __global__ __launch_bounds__(kStreamThreads) void step_stream_fused_kernel(Strea
                 integrate(U, F[k].x, F[k].y, F[k].z, m[k], 0.0f, 0.0f, 0.0f, x, y, z, vx, vy, vz);
                 X[k] = x; Y[k] = y; Z[k] = z; VX[k] = vx; VY[k] = vy; VZ[k] = vz;
             }
+        }
         }
         if (DIAG) {
 #pragma unroll
@@ -978,16 +1202,32 @@ __global__ __launch_bounds__(kBlockThreads) void cell_index_kernel(
     }
 }
 
-// field3[3c .. 3c+2] = field[c].xyz for the cells [first, first + count).
-__global__ __launch_bounds__(kBlockThreads) void pack_field3_kernel(
-    const f32x4* __restrict__ field, unsigned long long first, unsigned long long count, float* __restrict__ field3)
+// Whether a field cell lies inside the window of the packed path: every component zero or
+// within [2^-60, 2^60] in magnitude (NaN and infinities are outside).
+__device__ __forceinline__ bool cell_in_window(float x, float y, float z)
+{
+    auto ok = [](float v) { const float a = fabsf(v); return v == 0.0f || (a >= 0x1p-60f && a <= 0x1p60f); };
+    return ok(x) && ok(y) && ok(z);
+}
+
+// Brings what the streaming kernels need up to date with field[first, first + count): the copy
+// packed to 12 bytes per cell (field3[3c .. 3c+2] = field[c].xyz; null: not kept) and the flag
+// that tells them about components outside the packed path's window (set, never cleared here).
+__global__ __launch_bounds__(kBlockThreads) void prepare_field_kernel(
+    const f32x4* __restrict__ field, unsigned long long first, unsigned long long count, float* __restrict__ field3,
+    uint32_t* __restrict__ field_flag)
 {
     const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
+    bool bad = false;
     for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x; i < count; i += stride) {
         const f32x4 c = field[first + i];
-        float* o = field3 + 3ull * (first + i);
-        o[0] = c.x; o[1] = c.y; o[2] = c.z;
+        if (field3) {
+            float* o = field3 + 3ull * (first + i);
+            o[0] = c.x; o[1] = c.y; o[2] = c.z;
+        }
+        bad = bad || !cell_in_window(c.x, c.y, c.z);
     }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63u) == 0u) atomicOr(field_flag, 1u);
 }
 
 // ------------------------------------------------ indexed field patch K5
@@ -995,8 +1235,9 @@ __global__ __launch_bounds__(kBlockThreads) void pack_field3_kernel(
 // field[index[i]] = cells[i]: brush edits rewrite a list of cells
 // (src/cursor.rs:79-103 writes grid.grid[ix] for ix in modify_vector_indices).
 // `field3` (may be null): the packed copy, kept equal.
+// `field_flag` (may be null): see prepare_field_kernel; raised when a patched cell leaves the window.
 __global__ __launch_bounds__(kBlockThreads) void patch_field_kernel(
-    f32x4* __restrict__ field, float* __restrict__ field3, unsigned long long n_cells,
+    f32x4* __restrict__ field, float* __restrict__ field3, uint32_t* __restrict__ field_flag, unsigned long long n_cells,
     const uint32_t* __restrict__ index, const f32x4* __restrict__ cells, unsigned long long count)
 {
     const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
@@ -1007,6 +1248,7 @@ __global__ __launch_bounds__(kBlockThreads) void patch_field_kernel(
             const f32x4 v = cells[i];
             field[c] = v;
             if (field3) { field3[3ull * c] = v.x; field3[3ull * c + 1] = v.y; field3[3ull * c + 2] = v.z; }
+            if (field_flag && !cell_in_window(v.x, v.y, v.z)) atomicOr(field_flag, 1u);
         }
     }
 }
