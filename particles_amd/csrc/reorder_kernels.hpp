@@ -504,6 +504,7 @@ __device__ __forceinline__ void step_scatter_block(const StepScatterArgs& sa, co
             if (k < live) F[k] = fetch_cell(sa.field, sa.field3, ci[k]);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);   // the fetches are issued before anything below (see step4_packed)
     uint32_t key[4], rank[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

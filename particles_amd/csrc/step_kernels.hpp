@@ -293,6 +293,10 @@ __device__ __forceinline__ void step4_packed(const StepUniforms& U, const MassTa
     f32x4 F[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) F[k] = fetch(ci[k]);
+    // All four fetches leave before any arithmetic of the update: left alone, the scheduler moves the second
+    // pair's cell indices and fetches behind the first pair's update to save registers, and the lane pays
+    // two fetch round trips in a row (measured: 2.26 against 2.20 ms for 2^28 particles).
+    __builtin_amdgcn_sched_barrier(0);
     float2 mt[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { mt[k] = M.of((t4 >> (8 * k)) & 0xFFu); m[k] = mt[k].x; }
