@@ -382,14 +382,14 @@ int pcl_timer_stop(pcl_compute* h, float* elapsed_ms);
  * sits in, refreshed every `interval` steps by one counting-sort pass, so that
  * the per-particle field fetch stays cache-resident for fields larger than an
  * XCD's L2.  Per-particle results are unchanged bit for bit and every read
- * returns caller order.  interval: -1 automatic (default: every 16 steps for
+ * returns caller order.  interval: -1 automatic (default: every 24 steps for
  * fields above 16 KiB and at least 2^20 particles, except where the field is
  * staged in LDS: up to 64 KiB with 2^22 to 2^24 particles), 0 never, k > 0 every k steps. */
 int pcl_set_reorder_interval(pcl_compute* h, int interval);
 
 /* The interval currently in force: 0 when the order is not maintained (small
  * sets, fields small enough for LDS, or interval 0); in automatic mode it
- * starts at 16 and is paced by how far the particles drift between refreshes
+ * starts at 24 and is paced by how far the particles drift between refreshes
  * (a counting step reports how many tiles each block's particles fall into:
  * up to 3 doubles the interval, at most to 96; 8 or more halves it again). */
 int pcl_reorder_interval_in_use(const pcl_compute* h);

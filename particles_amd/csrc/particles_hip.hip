@@ -67,10 +67,12 @@ int fail(int code, const std::string& msg)
 
 constexpr size_t kStagingRecords = size_t(1) << 22;  // AoS staging chunk: 4 Mi records = 192 MiB
 constexpr uint32_t kLdsFieldMaxBytes = 64u * 1024u;  // fields up to this size are staged in LDS
-// Steps between refreshes of the tile order.  Fixed intervals on the headline workload: whole step 66.1 % of 8 TB/s
-// at 8, 67.0 at 12, 67.2 at 16 and 20, 66.9 at 24; 2^26 particles at initial speeds of 1-100 per axis: 16 within
-// 0.4 % of the best everywhere; 2^24 particles on a 256^2 field: 16-24 best (tools/intervalsweep.sh, driftsweep.sh).
-constexpr int kAutoReorderInterval = 16;
+// Steps between refreshes of the tile order.  Fixed intervals on the headline workload (2^28 particles, 1024^2 field;
+// whole step as a fraction of 8 TB/s): 10: 70.0 %, 12: 70.4, 16: 71.1, 20: 71.3, 24: 71.7, 32: 71.7, 40: 71.5, 48: 70.9,
+// 64: 69.2 (tools/intervalsweep.sh).  With few waves in flight the plain step hardly notices the age of the order
+// (2.186 ms at 10, 2.199 at 32), so the interval is set by the scatter step, which grows with it (3.6 ms at 10, 4.3 at 24,
+// 4.7 at 32, 6.2 at 64: a tile's particles spread over more bins).
+constexpr int kAutoReorderInterval = 24;
 constexpr size_t kPairWideMinParticles = size_t(1) << 18;   // below: the sort over many cells costs more than the sweep saves
 constexpr size_t kHistEntries = (size_t)pcl::kMaxReorderBins * pcl::kCursorGroups;   // counters (and cursors) in d_hist
 constexpr uint32_t kPairMaxCellsPerAxis = 64;          // cut-off cells per axis (beyond 20: counters in global memory)

@@ -724,7 +724,8 @@ __global__ __launch_bounds__(BLOCK, (DIAG && COUNT) ? 6 : 1) void step_stream_ke
     if (COUNT) {
         lds_barrier();   // LDS counters only: no need to drain the stores first
         // one tile per block in a counting launch; the ragged tail (block 0) counts with tile 0
-        const uint32_t count_group = blockIdx.x % a.hist_groups;
+        // (the counter group is that of the 2048-particle tile of the scatter step the block lies in)
+        const uint32_t count_group = (uint32_t)((unsigned long long)blockIdx.x * BLOCK / kStreamThreads) % a.hist_groups;
         uint32_t touched = 0u;
         for (uint32_t b = threadIdx.x; b < T.n_bins; b += BLOCK) {
             const uint32_t c = lds_hist[b];

@@ -627,7 +627,7 @@ def test_rejected_upload_leaves_a_tile_ordered_set_intact(oracle):
 @pytest.mark.parametrize("vel_extent,expect_long", [(0.0, True), (10.0, False)])
 def test_automatic_refresh_pacing_follows_the_drift(oracle, vel_extent, expect_long):
     """Automatic mode: particles that stay put stretch the refresh interval
-    (16 -> 32 -> 64 -> 96, each change one cycle after its measurement), fast ones keep it at 16; results are unaffected."""
+    (24 -> 48 -> 96, each change one cycle after its measurement), fast ones keep it at 24; results are unaffected."""
     sp = pa.SimParams()
     sp.delta_t = DT
     sp.force_grid_dimensions = (128, 128, 1)          # 256 KiB: too large for LDS staging
@@ -638,7 +638,7 @@ def test_automatic_refresh_pacing_follows_the_drift(oracle, vel_extent, expect_l
     with pa.Compute.new(pa.empty_particles(0), g) as c:
         c.update_sim_params(sp)
         c.generate_particles(n, seed=6, pos_extent=20.0, vel_extent=vel_extent)
-        assert c.reorder_interval_in_use == 16
+        assert c.reorder_interval_in_use == 24
         for _ in range(steps):
             c.compute()
         c.synchronize()
@@ -647,9 +647,9 @@ def test_automatic_refresh_pacing_follows_the_drift(oracle, vel_extent, expect_l
             want = oracle.run(sp, p, g, steps, mode=oracle.MODE_SKIP_INERT)
             assert_particles_bit_equal(c.read_particles(first, 2000), want, f"slice at {first}")
         if expect_long:
-            assert c.reorder_interval_in_use >= 64 and c.reorder_count <= 12       # against 21 at a fixed 16
+            assert c.reorder_interval_in_use >= 48 and c.reorder_count <= 9        # against 15 at a fixed 24
         else:
-            assert c.reorder_interval_in_use == 16 and c.reorder_count >= steps // 16 - 1
+            assert c.reorder_interval_in_use == 24 and c.reorder_count >= steps // 24 - 1
 
 
 # ---- BASELINE configuration 2 and the switch between the LDS-staged field and the tile order
@@ -662,7 +662,7 @@ def test_automatic_refresh_pacing_follows_the_drift(oracle, vel_extent, expect_l
 def test_config2_16m_particles_slices_match_oracle(oracle, n, dims, expect):
     """Particles generated on the device, swirl field, automatic settings, 26
     steps = more than one full refresh cycle of the tile order (scatter at steps 1
-    and 17, counting steps before them); slices of the result against the
+    and 25, counting steps before them); slices of the result against the
     oracle stepping the same global indices, and the cell indices bit-exact."""
     sp = pa.SimParams()
     sp.delta_t = DT
@@ -676,11 +676,11 @@ def test_config2_16m_particles_slices_match_oracle(oracle, n, dims, expect):
         if expect == "lds":
             assert c.reorder_interval_in_use == 0 and c.launch_geometry()["grid_blocks"] == 512
         else:
-            assert c.reorder_interval_in_use == 16
+            assert c.reorder_interval_in_use == 24
         for _ in range(steps):
             c.compute()
         assert c.last_step_kernel == pa.KERNEL_STREAM
-        # 2 refreshes at a fixed 16; the automatic pacing may stretch the interval after the first cycle
+        # 2 refreshes at a fixed 24 (the first one in two passes); the automatic pacing may stretch the interval after the first cycle
         assert (c.reorder_count == 0) if expect == "lds" else (c.reorder_count >= 2)
         for first in (0, 7654321, n // 2 - 2000, n - 4000):
             p = oracle.synth_particles(4000, seed=12345 + 2, first_global_index=first, pos_extent=20.0, vel_extent=10.0)
