@@ -424,6 +424,17 @@ int pcl_step_timing_read(pcl_compute* h, float* elapsed_ms, int32_t* kinds,
 int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks,
                         uint32_t* block_threads, uint32_t* particles_per_lane);
 
+/* Residency of the plain streaming step at its last launch (no counterpart in the
+ * reference).  The library limits how many blocks of that kernel are resident per
+ * CU by asking for dynamic LDS the kernel never touches (the memory system
+ * delivers more with fewer waves waiting on it); *intended is the limit the
+ * launch shape asked for (0: none), *granted what the HIP occupancy calculation
+ * reports for the kernel with that much LDS (with no limit: whatever fits).  When
+ * the two differ the limit is not used, and the mismatch is reported once on
+ * stderr and in pcl_last_error.  Both 0 before the first such launch. */
+int pcl_launch_residency(const pcl_compute* h, uint32_t* intended_blocks_per_cu,
+                         uint32_t* granted_blocks_per_cu);
+
 /* Tuning knobs for measurements (0 keeps the built-in defaults; results never
  * depend on them).  grid_blocks caps the grid of the streaming kernel (the
  * blocks then stride over the tiles).  variant is a bit set:
@@ -438,7 +449,10 @@ int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks,
  *   0x80000  the streaming step updates the particle arrays in place instead of ping-pong
  *   0xF000000  resident blocks per CU of the plain streaming step (1-12; 15 = as many as fit), and
  *   0x70000000 its block size (0: 512 threads, 1: 256, 2: 128, 3: 64); both zero = automatic
- *            (256 threads, 5 blocks per CU from 3 * 2^24 particles on; 512 threads, as many as fit below)
+ *            (256 threads, 3 blocks per CU from 2^23 particles on, 4 with fused diagnostics; 512 threads, as many as fit below)
+ *   0x300000 resident blocks per CU of the counting step (1-3; 0 = automatic)
+ *   0x4      the scalar path of the streaming kernels only (full divisions) instead of the packed one
+ *   0x200    particles in caller order are sorted once instead of twice before their first step
  *   0x40000  tests only: the next refresh of the particle order scatters with other keys than its
  *            histogram counted, which the kernel reports as PCL_ERR_DEVICE (the state is then unusable) */
 int pcl_set_tuning(pcl_compute* h, uint32_t grid_blocks, uint32_t variant);

@@ -99,6 +99,7 @@ SIGNATURES = {
     "pcl_step_timing_begin": (_i, [_vp, _sz]),
     "pcl_step_timing_read": (_i, [_vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "pcl_launch_geometry": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "pcl_launch_residency": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
     "pcl_set_reorder_interval": (_i, [_vp, _i]),
     "pcl_reorder_interval_in_use": (_i, [_vp]),
     "pcl_reorder_now": (_i, [_vp]),

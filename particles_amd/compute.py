@@ -365,6 +365,13 @@ class Compute:
         _lib.check(self._lib.pcl_launch_geometry(self._h, C.byref(g), C.byref(b), C.byref(p)))
         return {"grid_blocks": g.value, "block_threads": b.value, "particles_per_lane": p.value}
 
+    def launch_residency(self):
+        """Blocks per CU the plain streaming step's last launch asked for (0: no limit) and what the
+        runtime's occupancy calculation grants it."""
+        a, g = C.c_uint32(), C.c_uint32()
+        _lib.check(self._lib.pcl_launch_residency(self._h, C.byref(a), C.byref(g)))
+        return {"intended": a.value, "granted": g.value}
+
     def set_reorder_interval(self, interval):
         """-1 automatic, 0 never, k > 0: refresh the field-tile order every k steps."""
         _lib.check(self._lib.pcl_set_reorder_interval(self._h, int(interval)))

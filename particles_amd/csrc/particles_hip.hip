@@ -198,6 +198,10 @@ struct pcl_compute {
 
     uint32_t grid_cap = 0;  // 0: default
     uint32_t variant = 0;
+    // residency of the last plain streaming launch: blocks per CU the launch shape asked for (0: no cap)
+    // and what the runtime's occupancy calculation grants that kernel with the LDS it was launched with
+    uint32_t residency_intended = 0;
+    uint32_t residency_granted = 0;
 
     // state of the multi-GPU layer (particles_comm.hip), released in pcl_destroy
     void* comm = nullptr;
@@ -530,8 +534,30 @@ int allow_large_lds(K kernel, int device, size_t bytes)
     return allow_large_lds_impl(reinterpret_cast<const void*>(kernel), device, bytes);
 }
 
+// The cap is only as good as the runtime's LDS accounting (allocation granularity, bytes the runtime
+// reserves for itself): ask the occupancy calculation what it grants `kernel` in blocks of `block`
+// threads with `lds_bytes` of dynamic LDS, once per (kernel, device, LDS size).
+int granted_blocks_per_cu(const void* kernel, int device, int block, size_t lds_bytes, uint32_t* granted)
+{
+    struct Entry { const void* kernel; int device; size_t lds; uint32_t granted; };
+    static std::mutex mutex;
+    static std::vector<Entry> known;
+    std::lock_guard<std::mutex> lock(mutex);
+    for (const Entry& e : known)
+        if (e.kernel == kernel && e.device == device && e.lds == lds_bytes) { *granted = e.granted; return PCL_OK; }
+    int blocks = 0;
+    PCL_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, block, lds_bytes));
+    known.push_back(Entry{kernel, device, lds_bytes, (uint32_t)std::max(blocks, 0)});
+    *granted = known.back().granted;
+    return PCL_OK;
+}
+
 // Plain streaming step (field through the caches, no histogram) in blocks of BLOCK threads,
 // one tile of 4 * BLOCK particles per block, at most `cap` blocks per CU (0: whatever fits).
+// A cap that the runtime does not grant exactly (fewer blocks: registers or wave slots bind first;
+// more: the LDS accounting has changed) is not used: the launch falls back to no cap, the handle
+// records what was asked and what was granted (pcl_launch_residency) and the mismatch is reported
+// once per process on stderr and in pcl_last_error.
 template <bool DIAG, bool NT, int BLOCK>
 int launch_plain_shaped(pcl_compute* h, const pcl::StreamArgs& a, const pcl::StepUniforms& U, const pcl::TileMap& T, uint32_t cap,
                         uint32_t& grid)
@@ -543,8 +569,24 @@ int launch_plain_shaped(pcl_compute* h, const pcl::StreamArgs& a, const pcl::Ste
         if (int rc = reserve_partials(h, (uint32_t)tiles)) return rc;
     pcl::StreamArgs args = a;
     args.partials = h->d_partials;
-    const size_t pad = occupancy_pad(cap, 0);
-    if (int rc = allow_large_lds(pcl::step_stream_kernel<DIAG, NT, false, false, BLOCK>, h->device, pad)) return rc;
+    const void* kernel = reinterpret_cast<const void*>(pcl::step_stream_kernel<DIAG, NT, false, false, BLOCK>);
+    size_t pad = occupancy_pad(cap, 0);
+    if (int rc = allow_large_lds_impl(kernel, h->device, pad)) return rc;
+    uint32_t granted = 0;
+    if (int rc = granted_blocks_per_cu(kernel, h->device, BLOCK, pad, &granted)) return rc;
+    h->residency_intended = cap;
+    h->residency_granted = granted;
+    if (cap != 0 && granted != cap) {
+        static bool reported = false;
+        g_last_error = "the residency cap of the streaming step asked for " + std::to_string(cap) + " blocks of " +
+                       std::to_string(BLOCK) + " threads per CU with " + std::to_string(pad) +
+                       " bytes of dynamic LDS, the runtime grants " + std::to_string(granted) + ": launching without the cap";
+        if (!reported) {
+            std::fprintf(stderr, "particles_hip: %s\n", g_last_error.c_str());
+            reported = true;
+        }
+        pad = 0;
+    }
     hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, false, false, BLOCK>), dim3((uint32_t)tiles), dim3(BLOCK),
                        pad, h->stream, args, U, T);
     PCL_HIP_TRY(hipGetLastError());
@@ -2119,6 +2161,14 @@ int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks, uint32_t* b
     if (grid_blocks) *grid_blocks = blocks;
     if (block_threads) *block_threads = threads;
     if (particles_per_lane) *particles_per_lane = pcl::kParticlesPerLane;
+    return PCL_OK;
+}
+
+int pcl_launch_residency(const pcl_compute* h, uint32_t* intended_blocks_per_cu, uint32_t* granted_blocks_per_cu)
+{
+    if (!h) return fail(PCL_ERR_INVALID, "null handle");
+    if (intended_blocks_per_cu) *intended_blocks_per_cu = h->residency_intended;
+    if (granted_blocks_per_cu) *granted_blocks_per_cu = h->residency_granted;
     return PCL_OK;
 }
 
