@@ -4,24 +4,30 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one launch of the update over every resident particle
-(``Compute::compute`` of the reference, src/compute.rs:221-227).  Workload per
-GPU (weak scaling): 2^28 particles, 1024 x 1024 x 1 field, the 256M-particle
-configuration the HBM target is quoted on; seeded synthetic inputs generated
-on the device: pos uniform over the whole bounding cube (worst case for the
-field fetch), vel = 10*(u-0.5), ty = i % 5, masses (1, .5, 2, 1.5, .75), zero
-force curves (the reference's default, so the streaming kernel runs), dt = 1/60.
-For N > 1 the script runs once per GPU: started by torch.distributed.run
-(RANK/WORLD_SIZE in the environment), or, when started plainly as
-``python bench.py --gpus N``, it starts torch.distributed.run itself as a child
-process (before anything here touches the GPU) and exits with its status.
-Ranks own disjoint index ranges, the field is created on rank 0 and replicated
-with one RCCL broadcast, and (with --diagnostics on) the per-step diagnostics
-are all-reduced.  Rank 0 prints one JSON line.
+(``Compute::compute`` of the reference, src/compute.rs:221-227).  Workload:
+BASELINE configuration 3, 2^28 particles on a 1024 x 1024 x 1 field, the
+256M-particle configuration the HBM target is quoted on, particle-sharded over
+the N GPUs (strong scaling: the 2^28 are split); seeded synthetic inputs
+generated on the device: pos uniform over the whole bounding cube (worst case
+for the field fetch), vel = 10*(u-0.5), ty = i % 5, masses (1, .5, 2, 1.5, .75),
+zero force curves (the reference's default, so the streaming kernel runs),
+dt = 1/60.  For N > 1 the script runs once per GPU: started by
+torch.distributed.run (RANK/WORLD_SIZE in the environment), or, when started
+plainly as ``python bench.py --gpus N``, it starts torch.distributed.run itself
+as a child process (before anything here touches the GPU) and exits with its
+status.  Ranks own disjoint index ranges; the field is created on rank 0 and
+replicated with one RCCL broadcast issued INSIDE the library (pcl_comm_*: the
+calls a Rust or C host would make; ``--collectives torch`` routes them through
+torch.distributed instead), and with diagnostics on the per-step record is
+all-reduced.  The process group only carries the communicator's unique id and
+this script's own timing exchange.  Rank 0 prints one JSON line.
 
-Scaling: ``--scaling weak`` (default) keeps --particles-per-gpu per rank;
-``--scaling strong --total-particles T`` splits T over the ranks
-(BASELINE configuration 3: T = 2^28 over 1/2/4/8 GPUs; configuration 4:
-``--gpus 8 --scaling strong --total-particles 1073741824 --diagnostics on``).
+With N > 1 and no explicit workload flags the same invocation also times, after
+the headline, the weak-scaling case (2^28 particles on EVERY GPU) and, at
+N = 8, BASELINE configuration 4 (2^30 particles, diagnostics all-reduced every
+step); they appear under "also" in the line, never as "value".
+``--scaling weak|strong``, ``--particles-per-gpu``, ``--total-particles`` select
+one explicit case instead.
 """
 import argparse
 import json
@@ -69,17 +75,16 @@ def make_params(pa, dims, masses=MASSES):
 
 
 def measured_traffic(n_local, dims, pos_extent):
-    """HBM bytes per launch of the step kernel: a STORED figure from the committed
-    rocprofv3 PMC passes (profiles/traffic.json, which names the pass files), looked
-    up by workload; None when this workload was not profiled.  Not measured in this run:
-    counters need rocprofv3 around the process."""
+    """HBM bytes per launch of the step kernels: STORED figures from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, which names the pass files), looked up by workload; {} when this workload was
+    not profiled.  Keys: hbm_bytes (the plain step kernel), kernels (per launch kind), source.  Not measured
+    in this run: counters need rocprofv3 around the process."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             table = json.load(f)
-        rec = table.get(f"{n_local}|{dims[0]}x{dims[1]}x{dims[2]}|{float(pos_extent)}")
-        return (rec["hbm_bytes"], rec.get("source")) if rec else (None, None)
+        return table.get(f"{n_local}|{dims[0]}x{dims[1]}x{dims[2]}|{float(pos_extent)}") or {}
     except (OSError, ValueError, KeyError):
-        return None, None
+        return {}
 
 
 def cpu_baseline(sp, field, seed, pos_extent, budget_s=12.0):
@@ -145,11 +150,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--particles-per-gpu", type=int, default=1 << 28)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: --particles-per-gpu on every rank; strong: --total-particles split over the ranks")
-    ap.add_argument("--total-particles", type=int, default=1 << 28,
-                    help="strong scaling only: the whole set (2^28 = configuration 3, 2^30 over 8 GPUs = configuration 4)")
+    ap.add_argument("--particles-per-gpu", type=int, default=None,
+                    help="weak scaling: this many particles on every rank (default 2^28)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="weak: --particles-per-gpu on every rank; strong: --total-particles split over the ranks "
+                         "(default: strong, configuration 3; giving --particles-per-gpu alone selects weak)")
+    ap.add_argument("--total-particles", type=int, default=None,
+                    help="strong scaling: the whole set (default 2^28 = configuration 3; 2^30 over 8 GPUs = configuration 4)")
     ap.add_argument("--field", type=int, nargs=3, default=(1024, 1024, 1), metavar=("NX", "NY", "NZ"))
     ap.add_argument("--pos-extent", type=float, default=2.0 * RADIUS,
                     help="positions are pos_extent*(u-0.5); 20 = whole cube, 2 = the reference's cluster")
@@ -172,12 +179,13 @@ def main():
     ap.add_argument("--edits", action="store_true",
                     help="every step a brush (src/cursor.rs, Shift mode) rewrites the cells within falloff_dist of a "
                          "moving cursor on the device field; rank 0's cursor record is broadcast before the step")
-    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
-                    help="process-group backend: nccl is RCCL over xGMI; gloo stages every collective through the host "
-                         "and admits several ranks on one GPU (a rehearsal of the multi-rank path on a one-GPU box)")
-    ap.add_argument("--collectives", choices=("torch", "native"), default="torch",
-                    help="torch: torch.distributed calls (backend nccl is RCCL); native: RCCL called inside the library "
-                         "on the handle's own stream (pcl_comm_*), the process group only carries the unique id")
+    ap.add_argument("--collectives", choices=("native", "torch"), default="native",
+                    help="native: RCCL called inside the library on the handle's own stream (pcl_comm_*), the process "
+                         "group only carries the unique id; torch: torch.distributed calls (backend nccl is RCCL)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default=None,
+                    help="process-group backend (default: gloo with native collectives, where it is control plane only; "
+                         "nccl with torch collectives).  torch collectives over gloo stage everything through the host "
+                         "and admit several ranks on one GPU (a rehearsal of the multi-rank path on a one-GPU box)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="use the RCCL broadcast/all-reduce path even with one rank (when started by torch.distributed.run)")
     args = ap.parse_args()
@@ -202,7 +210,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus disagree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    device_index = local_rank % torch.cuda.device_count()   # one GPU per rank; wraps only in a gloo rehearsal
+    if args.backend is None:
+        args.backend = "gloo" if args.collectives == "native" else "nccl"
+    device_index = local_rank % torch.cuda.device_count()   # one GPU per rank; wraps only in a rehearsal on fewer GPUs
     if args.backend == "nccl" and local_rank >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: RCCL needs one GPU per rank ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(device_index)
@@ -211,26 +221,63 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group("gloo")
-    reduce_device = "cuda" if args.backend == "nccl" else "cpu"
+    ctx = {"torch": torch, "dist": dist, "pa": pa, "world": world, "rank": rank, "device_index": device_index,
+           "reduce_device": "cuda" if args.backend == "nccl" else "cpu"}
 
+    # Which cases run: an explicit one (any workload flag given), or the headline and its companions.
+    explicit = args.scaling is not None or args.particles_per_gpu is not None or args.total_particles is not None
+    if args.scaling is None:
+        args.scaling = "weak" if (args.particles_per_gpu is not None and args.total_particles is None) else "strong"
+    per_gpu = args.particles_per_gpu if args.particles_per_gpu is not None else 1 << 28
+    total = args.total_particles if args.total_particles is not None else 1 << 28
+    headline = {"scaling": args.scaling, "n_total": total if args.scaling == "strong" else per_gpu * world,
+                "diag_on": args.diagnostics == "on", "with_cpu_baseline": world == 1 and not args.no_cpu_baseline}
+    out = run_case(args, ctx, **headline)
+    if world > 1 and not explicit and not args.edits:
+        also = {"weak_scaling": run_case(args, ctx, scaling="weak", n_total=(1 << 28) * world,
+                                         diag_on=args.diagnostics == "on", with_cpu_baseline=False)}
+        if world == 8:
+            also["configuration_4"] = run_case(args, ctx, scaling="strong", n_total=1 << 30, diag_on=True, with_cpu_baseline=False)
+        if rank == 0:
+            out["also"] = {k: {f: v[f] for f in ("value", "unit", "ms_per_step", "scaling", "rccl_ranks",
+                                                 "kernel_ms_per_rank", "config", "roofline", "final_diagnostics")}
+                           for k, v in also.items()}
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def run_case(args, ctx, *, scaling, n_total, diag_on, with_cpu_baseline):
+    """One timed case: builds the sharded scene, warms up, times args.steps steps between fences and returns the
+    result record on rank 0 (None elsewhere)."""
+    torch, dist, pa = ctx["torch"], ctx["dist"], ctx["pa"]
+    world, rank, device_index, reduce_device = ctx["world"], ctx["rank"], ctx["device_index"], ctx["reduce_device"]
     dims = tuple(args.field)
     n_cells = dims[0] * dims[1] * dims[2]
-    n_total = args.total_particles if args.scaling == "strong" else args.particles_per_gpu * world
     sp = make_params(pa, dims, args.masses)
 
     # Field: built on rank 0, replicated by ShardedCompute with one broadcast over RCCL;
     # every rank fills its own index range with the seeded scene on the device.
     field_host = swirl_field(*dims, RADIUS, args.seed) if rank == 0 else None
-    sc = pa.ShardedCompute.new(None, field_host, n_total=n_total, seed=args.seed,
-                               pos_extent=args.pos_extent, vel_extent=args.vel_extent, device=device_index,
-                               force_collectives=args.force_collectives, collectives=args.collectives, n_cells=n_cells)
+    # one process and nobody to talk to: no communicator is formed at all (the field goes straight to the handle)
+    collectives = args.collectives if dist.is_initialized() else "torch"
+    try:
+        sc = pa.ShardedCompute.new(None, field_host, n_total=n_total, seed=args.seed,
+                                   pos_extent=args.pos_extent, vel_extent=args.vel_extent, device=device_index,
+                                   force_collectives=args.force_collectives, collectives=collectives, n_cells=n_cells)
+    except pa.PclError as e:
+        # no fallback to another collective path: what the library's RCCL said is the result
+        raise SystemExit(f"rank {rank}: setting up the sharded scene with --collectives {collectives} failed: {e}")
     n_local = sc.num_local_particles        # this rank's index range [g*N/G, (g+1)*N/G)
-    assert args.scaling == "strong" or n_local == args.particles_per_gpu
     c = sc.local
+    # which physical device this rank runs on, and how many ranks the library's communicator counts
+    print(f"bench.py rank {rank}/{world}: device {device_index} pci {c.pci_bus_id} particles {n_local} "
+          f"library communicator ranks {c.comm_count}", file=sys.stderr, flush=True)
     c.set_tuning(args.grid_blocks, args.variant)
     c.set_reorder_interval(args.reorder_interval)
     sc.update_sim_params(sp)
-    diag_on = args.diagnostics == "on"
     sc.enable_step_diagnostics(diag_on)
 
     brush = None
@@ -287,8 +334,8 @@ def main():
         per_rank_kernel_ms = [float(e[1]) for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms, region_ms = float(t[0]), float(t[1]), float(t[2])
-    if args.collectives == "native":
-        rccl_ranks = int(c._lib.pcl_comm_world(c._h))        # the library's own communicator
+    if collectives == "native":
+        rccl_ranks = c.comm_count                            # ncclCommCount of the library's own communicator
     else:
         rccl_ranks = dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0
 
@@ -313,17 +360,19 @@ def main():
 
     diag = sc.diagnostics()      # collective: global count / kinetic energy / bounds
     geometry = c.launch_geometry()
+    geometry["resident_blocks_per_cu"] = c.launch_residency()
     kernel = c.last_step_kernel
 
+    out = None
     if rank == 0:
         total = n_total
         value = total * args.steps / elapsed
         # rank 0's own launches over rank 0's own range
         achieved = n_local * BYTES_PER_PARTICLE_STEP / (kernel_ms_local * 1e-3) / 1e9
         whole = n_local * BYTES_PER_PARTICLE_STEP / (region_ms * 1e-3) / 1e9
-        if args.scaling == "strong" and total == 1 << 28 and dims == (1024, 1024, 1):
-            which = "BASELINE configuration 3 (256M particles, 1024x1024 field, particle-sharded)"
-        elif args.scaling == "strong" and total == 1 << 30 and dims == (1024, 1024, 1) and diag_on:
+        if scaling == "strong" and total == 1 << 28 and dims == (1024, 1024, 1) and world > 1:
+            which = f"BASELINE configuration 3 (256M particles, 1024x1024 field, particle-sharded over {world} GPUs, strong scaling)"
+        elif scaling == "strong" and total == 1 << 30 and dims == (1024, 1024, 1) and diag_on:
             which = "BASELINE configuration 4 (1B particles, diagnostics all-reduce per step)"
         elif world == 1 and total == 1 << 28 and dims == (1024, 1024, 1):
             which = "BASELINE configuration 3 at one GPU (256M particles, 1024x1024 field)"
@@ -331,12 +380,13 @@ def main():
             which = "BASELINE configuration 2 (16M particles, 256x256 field)"
         elif total == 1 << 26 and args.edits:
             which = "BASELINE configuration 5 (64M particles, per-frame brush edits)"
-        elif args.scaling == "weak" and args.particles_per_gpu == 1 << 28 and dims == (1024, 1024, 1):
-            which = "configuration 3's per-GPU load on every GPU (weak scaling: 2^28 particles per GPU)"
+        elif scaling == "weak" and n_local == 1 << 28 and dims == (1024, 1024, 1):
+            which = "configuration 3's one-GPU load on every GPU (weak scaling: 2^28 particles per GPU)"
         else:
             which = "custom"
         # the launches that also refresh the particle order move more bytes per particle:
         # counting step 49 B (same traffic, extra LDS histogram), scatter step 49 B + 4 B index read + 4 B index write + 1 B type write
+        traffic_table = measured_traffic(n_local, dims, args.pos_extent) if args.vel_extent == 10.0 else {}
         kernel_rooflines = []
         for k, name, nbytes in ((1, "step_stream_kernel", 49), (2, "step_pairs_kernel", 49),
                                 (3, "step_stream_kernel+count", 49), (4, "step_scatter_kernel", 58)):
@@ -344,8 +394,9 @@ def main():
             if ms:
                 a = n_local * nbytes / (ms * 1e-3) / 1e9
                 kernel_rooflines.append({"kernel": name, "launches": by_kind[name]["launches"], "avg_ms": ms,
-                                         "bytes_per_particle": nbytes, "achieved": a, "frac": a / HBM_PEAK_GBS})
-        traffic, traffic_source = measured_traffic(n_local, dims, args.pos_extent) if args.vel_extent == 10.0 else (None, None)
+                                         "bytes_per_particle": nbytes, "achieved": a, "frac": a / HBM_PEAK_GBS,
+                                         "traffic": (traffic_table.get("kernels") or {}).get(name)})
+        traffic, traffic_source = traffic_table.get("hbm_bytes"), traffic_table.get("source")
         out = {
             "metric": "particle-steps/sec",
             "value": value,
@@ -355,7 +406,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -374,8 +425,11 @@ def main():
                 "reorder_interval": args.reorder_interval,
                 "reorder_passes_in_timed_region": reorders_timed,
                 "parallelism": f"particle-sharded x{world}, field replicated by "
-                               + ("RCCL broadcast inside the library" if args.collectives == "native" else
-                                  "RCCL broadcast" if args.backend == "nccl" else "gloo broadcast (host-staged rehearsal)"),
+                               + ("no collective (one process)" if not dist.is_initialized() else
+                                  "RCCL broadcast inside the library (pcl_comm_*)" if collectives == "native" else
+                                  "RCCL broadcast through torch.distributed" if args.backend == "nccl" else
+                                  "gloo broadcast (host-staged rehearsal)"),
+                "collectives": collectives if dist.is_initialized() else "none",
                 "kernel": {1: "step_stream_kernel", 2: "step_pairs_kernel"}.get(kernel, "none"),
                 "launch": geometry,
             },
@@ -399,21 +453,18 @@ def main():
                         "(HIP event pair per launch on the kernel's stream, rank 0). whole_step_frac / whole_region: "
                         "49 B per particle over the HIP-event time of the whole timed region / steps, i.e. including "
                         "the counting and scatter launches that refresh the particle order. kernels: every launch "
-                        "kind of the timed region with its own byte count",
+                        "kind of the timed region with its own byte count and, where profiled, its counter-derived "
+                        "HBM bytes per launch (stored figures)",
             },
             "final_diagnostics": {"count": diag["count"], "kinetic_energy": diag["kinetic_energy"]},
         }
         if fused is not None:
             out["fused_stepping"] = fused
-        if world == 1 and not args.no_cpu_baseline:
+        if with_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sp, field_host, args.seed, args.pos_extent)
             out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-
     sc.close()
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

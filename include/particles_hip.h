@@ -420,6 +420,10 @@ int pcl_step_timing_begin(pcl_compute* h, size_t max_steps);
 int pcl_step_timing_read(pcl_compute* h, float* elapsed_ms, int32_t* kinds,
                          size_t capacity, size_t* count);
 
+/* PCI bus id of the handle's GPU ("0000:c1:00.0"), for reports that must show
+ * which physical devices the ranks of a job ran on.  capacity >= 16. */
+int pcl_device_pci_bus_id(const pcl_compute* h, char* out, size_t capacity);
+
 /* Geometry of the streaming kernel's launch (for reports). */
 int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks,
                         uint32_t* block_threads, uint32_t* particles_per_lane);
@@ -519,6 +523,10 @@ int pcl_comm_attach(pcl_compute* h, const void* unique_id, int rank, int world);
 int pcl_comm_detach(pcl_compute* h);          /* pcl_destroy does it too */
 int pcl_comm_rank(const pcl_compute* h);      /* -1 without a communicator */
 int pcl_comm_world(const pcl_compute* h);     /*  0 without a communicator */
+/* The rank count as the communicator itself reports it (ncclCommCount): what RCCL
+ * saw, as opposed to what pcl_comm_attach was told; 0 without a communicator,
+ * -1 when the query fails. */
+int pcl_comm_count(const pcl_compute* h);
 
 /* Compute::update_force_grid (src/compute.rs:198-204) on every replica: the
  * root's cells are broadcast straight into each handle's field. */

@@ -99,6 +99,7 @@ SIGNATURES = {
     "pcl_step_timing_begin": (_i, [_vp, _sz]),
     "pcl_step_timing_read": (_i, [_vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "pcl_launch_geometry": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "pcl_device_pci_bus_id": (_i, [_vp, C.c_char_p, _sz]),
     "pcl_launch_residency": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
     "pcl_set_reorder_interval": (_i, [_vp, _i]),
     "pcl_reorder_interval_in_use": (_i, [_vp]),
@@ -118,6 +119,7 @@ SIGNATURES = {
     "pcl_comm_detach": (_i, [_vp]),
     "pcl_comm_rank": (_i, [_vp]),
     "pcl_comm_world": (_i, [_vp]),
+    "pcl_comm_count": (_i, [_vp]),
     "pcl_comm_update_force_grid": (_i, [_vp, _vp, _sz, _i]),
     "pcl_comm_patch_force_grid": (_i, [_vp, _sz, _vp, _sz, _i]),
     "pcl_comm_patch_force_grid_indexed": (_i, [_vp, _vp, _vp, _sz, _i]),

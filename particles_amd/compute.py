@@ -365,6 +365,17 @@ class Compute:
         _lib.check(self._lib.pcl_launch_geometry(self._h, C.byref(g), C.byref(b), C.byref(p)))
         return {"grid_blocks": g.value, "block_threads": b.value, "particles_per_lane": p.value}
 
+    @property
+    def pci_bus_id(self):
+        buf = C.create_string_buffer(64)
+        _lib.check(self._lib.pcl_device_pci_bus_id(self._h, buf, 64))
+        return buf.value.decode()
+
+    @property
+    def comm_count(self):
+        """Ranks of the attached communicator as RCCL itself counts them (0: none attached)."""
+        return int(self._lib.pcl_comm_count(self._h))
+
     def launch_residency(self):
         """Blocks per CU the plain streaming step's last launch asked for (0: no limit) and what the
         runtime's occupancy calculation grants it."""

@@ -13,7 +13,14 @@
 //     of all-reduces over the 48-byte record (sum of count and kinetic energy
 //     in f64, max of the six f32 bounds).
 // Every collective is enqueued on the handle's own stream, so it is ordered
-// with the kernels before and after it without host synchronisation.
+// with the kernels before and after it without host synchronisation.  One
+// exception: with the pair term active and one process per rank, every step
+// first agrees on the length the ranges are padded to (an all-reduce of the
+// local particle counts, read back on the host: max_local_count); a process
+// that drives the whole group knows every count and skips that.
+// All ranks must hold the same parameters: which collectives a step issues
+// follows from them (pair term active or not, step diagnostics on or off),
+// and ranks that disagree wait for each other's missing calls.
 //
 // Two ways to form the communicator: one process (or thread) per GPU attaches
 // its handle with a shared unique id (pcl_comm_attach: ncclCommInitRank), or
@@ -54,6 +61,7 @@ struct Rccl {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
@@ -91,6 +99,7 @@ void load_rccl()
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
     r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
     r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
@@ -183,8 +192,35 @@ struct Span {
     int n;
 };
 
-int group_begin(const Span& s) { if (s.n > 1) PCL_NCCL_TRY(g_rccl.GroupStart()); return PCL_OK; }
-int group_end(const Span& s) { if (s.n > 1) PCL_NCCL_TRY(g_rccl.GroupEnd()); return PCL_OK; }
+// One ncclGroupStart/End pair around the collectives a call issues (needed as soon as one thread drives
+// more than one communicator).  The group is closed on every way out of the scope: left open by an early
+// return, it would swallow every later collective of the thread (queued, never launched), and the next
+// synchronisation would hang.  The first error stays the call's result.
+class GroupScope {
+    bool open_ = false;
+
+public:
+    GroupScope() = default;
+    GroupScope(const GroupScope&) = delete;
+    GroupScope& operator=(const GroupScope&) = delete;
+    ~GroupScope() { if (open_) (void)g_rccl.GroupEnd(); }
+    int begin(bool needed)
+    {
+        if (needed) {
+            PCL_NCCL_TRY(g_rccl.GroupStart());
+            open_ = true;
+        }
+        return PCL_OK;
+    }
+    int end()
+    {
+        if (open_) {
+            open_ = false;
+            PCL_NCCL_TRY(g_rccl.GroupEnd());
+        }
+        return PCL_OK;
+    }
+};
 
 int check_span(const Span& s)
 {
@@ -212,14 +248,15 @@ int bcast_cells(const Span& s, const float (*host_cells)[4], size_t first_cell, 
         PCL_REQUIRE(host_cells != nullptr, "the root rank passed no cells");
         if (int rc = pcl_patch_force_grid(r, first_cell, host_cells, count)) return rc;   // host -> root's field (synchronises)
     }
-    if (int rc = group_begin(s)) return rc;
+    GroupScope group;
+    if (int rc = group.begin(s.n > 1)) return rc;
     for (int i = 0; i < s.n; ++i) {
         pcl_compute* h = s.h[i];
         if (int rc = pcl_internal::make_current(h)) return rc;
         float* at = static_cast<float*>(pcl_internal::field_of(h)) + 4 * first_cell;
         PCL_NCCL_TRY(g_rccl.Broadcast(at, at, count * 4, ncclFloat, root, comm_of(h)->comm, pcl_internal::stream_of(h)));
     }
-    return group_end(s);
+    return group.end();
 }
 
 int update_force_grid(const Span& s, const float (*grid)[4], size_t n_cells, int root)
@@ -275,14 +312,17 @@ int patch_force_grid_indexed(const Span& s, const uint32_t* idx, const float (*c
         PCL_HIP_TRY(hipMemcpyAsync(c->d_stage + count * 16, idx, count * 4, hipMemcpyHostToDevice, pcl_internal::stream_of(r)));
         PCL_HIP_TRY(hipStreamSynchronize(pcl_internal::stream_of(r)));   // the caller's buffers are only valid during the call
     }
-    if (int rc = group_begin(s)) return rc;
-    for (int i = 0; i < s.n; ++i) {
-        pcl_compute* h = s.h[i];
-        Comm* c = comm_of(h);
-        if (int rc = pcl_internal::make_current(h)) return rc;
-        PCL_NCCL_TRY(g_rccl.Broadcast(c->d_stage, c->d_stage, bytes, ncclChar, root, c->comm, pcl_internal::stream_of(h)));
+    {
+        GroupScope group;
+        if (int rc = group.begin(s.n > 1)) return rc;
+        for (int i = 0; i < s.n; ++i) {
+            pcl_compute* h = s.h[i];
+            Comm* c = comm_of(h);
+            if (int rc = pcl_internal::make_current(h)) return rc;
+            PCL_NCCL_TRY(g_rccl.Broadcast(c->d_stage, c->d_stage, bytes, ncclChar, root, c->comm, pcl_internal::stream_of(h)));
+        }
+        if (int rc = group.end()) return rc;
     }
-    if (int rc = group_end(s)) return rc;
     for (int i = 0; i < s.n; ++i) {
         Comm* c = comm_of(s.h[i]);
         if (int rc = pcl_patch_force_grid_indexed_device(s.h[i], c->d_stage + count * 16, c->d_stage, count)) return rc;
@@ -303,15 +343,18 @@ int brush_event(const Span& s, const pcl_brush_input* in, int root, bool down)
                                    pcl_internal::stream_of(r)));
         PCL_HIP_TRY(hipStreamSynchronize(pcl_internal::stream_of(r)));
     }
-    if (int rc = group_begin(s)) return rc;
-    for (int i = 0; i < s.n; ++i) {
-        pcl_compute* h = s.h[i];
-        Comm* c = comm_of(h);
-        if (int rc = pcl_internal::make_current(h)) return rc;
-        PCL_NCCL_TRY(g_rccl.Broadcast(c->d_record, c->d_record, sizeof(pcl_brush_input), ncclChar, root, c->comm,
-                                      pcl_internal::stream_of(h)));
+    {
+        GroupScope group;
+        if (int rc = group.begin(s.n > 1)) return rc;
+        for (int i = 0; i < s.n; ++i) {
+            pcl_compute* h = s.h[i];
+            Comm* c = comm_of(h);
+            if (int rc = pcl_internal::make_current(h)) return rc;
+            PCL_NCCL_TRY(g_rccl.Broadcast(c->d_record, c->d_record, sizeof(pcl_brush_input), ncclChar, root, c->comm,
+                                          pcl_internal::stream_of(h)));
+        }
+        if (int rc = group.end()) return rc;
     }
-    if (int rc = group_end(s)) return rc;
     for (int i = 0; i < s.n; ++i) {
         const int rc = down ? pcl_brush_mouse_down_device(s.h[i], comm_of(s.h[i])->d_record)
                             : pcl_brush_mouse_moved_device(s.h[i], comm_of(s.h[i])->d_record);
@@ -327,28 +370,32 @@ int allreduce_diagnostics(const Span& s)
     std::vector<const void*> local(s.n, nullptr);
     for (int i = 0; i < s.n; ++i)
         if (int rc = pcl_internal::diagnostics_on_device(s.h[i], &local[i])) return rc;
-    PCL_NCCL_TRY(g_rccl.GroupStart());
+    GroupScope group;   // always: two all-reduces per handle travel as one call
+    if (int rc = group.begin(true)) return rc;
     for (int i = 0; i < s.n; ++i) {
         pcl_compute* h = s.h[i];
         Comm* c = comm_of(h);
-        if (int rc = pcl_internal::make_current(h)) { (void)g_rccl.GroupEnd(); return rc; }
+        if (int rc = pcl_internal::make_current(h)) return rc;
         const char* in = static_cast<const char*>(local[i]);
         char* out = reinterpret_cast<char*>(c->d_global);
-        ncclResult_t r = g_rccl.AllReduce(in, out, 2, ncclDouble, ncclSum, c->comm, pcl_internal::stream_of(h));
-        if (r == ncclSuccess)
-            r = g_rccl.AllReduce(in + 16, out + 16, 6, ncclFloat, ncclMax, c->comm, pcl_internal::stream_of(h));
-        if (r != ncclSuccess) {
-            (void)g_rccl.GroupEnd();
-            return fail(PCL_ERR_COMM, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
-        }
+        PCL_NCCL_TRY(g_rccl.AllReduce(in, out, 2, ncclDouble, ncclSum, c->comm, pcl_internal::stream_of(h)));
+        PCL_NCCL_TRY(g_rccl.AllReduce(in + 16, out + 16, 6, ncclFloat, ncclMax, c->comm, pcl_internal::stream_of(h)));
     }
-    PCL_NCCL_TRY(g_rccl.GroupEnd());
-    return PCL_OK;
+    return group.end();
 }
 
 // Largest local particle count over all ranks (what every range is padded to in the all-gather).
+// A span that holds every rank (one process driving the whole group) knows it without asking; one
+// process per rank needs an all-reduce and a host synchronisation, per step: a rank cannot know that
+// another rank's count has changed.
 int max_local_count(const Span& s, size_t* out)
 {
+    if (s.n == comm_of(s.h[0])->world) {
+        size_t most = 0;
+        for (int i = 0; i < s.n; ++i) most = std::max(most, pcl_num_particles(s.h[i]));
+        *out = most;
+        return PCL_OK;
+    }
     for (int i = 0; i < s.n; ++i) {
         pcl_compute* h = s.h[i];
         Comm* c = comm_of(h);
@@ -357,14 +404,17 @@ int max_local_count(const Span& s, size_t* out)
         PCL_HIP_TRY(hipMemcpyAsync(c->d_count, c->h_count, sizeof(unsigned long long), hipMemcpyHostToDevice,
                                    pcl_internal::stream_of(h)));
     }
-    if (int rc = group_begin(s)) return rc;
-    for (int i = 0; i < s.n; ++i) {
-        pcl_compute* h = s.h[i];
-        Comm* c = comm_of(h);
-        if (int rc = pcl_internal::make_current(h)) return rc;
-        PCL_NCCL_TRY(g_rccl.AllReduce(c->d_count, c->d_count, 1, ncclUint64, ncclMax, c->comm, pcl_internal::stream_of(h)));
+    {
+        GroupScope group;
+        if (int rc = group.begin(s.n > 1)) return rc;
+        for (int i = 0; i < s.n; ++i) {
+            pcl_compute* h = s.h[i];
+            Comm* c = comm_of(h);
+            if (int rc = pcl_internal::make_current(h)) return rc;
+            PCL_NCCL_TRY(g_rccl.AllReduce(c->d_count, c->d_count, 1, ncclUint64, ncclMax, c->comm, pcl_internal::stream_of(h)));
+        }
+        if (int rc = group.end()) return rc;
     }
-    if (int rc = group_end(s)) return rc;
     for (int i = 0; i < s.n; ++i) {
         pcl_compute* h = s.h[i];
         Comm* c = comm_of(h);
@@ -413,15 +463,18 @@ int step(const Span& s)
                 }
                 if (int rc = pcl_pack_pair_sources_device(h, c->d_pair_send, cap)) return rc;
             }
-            if (int rc = group_begin(s)) return rc;
-            for (int i = 0; i < s.n; ++i) {
-                pcl_compute* h = s.h[i];
-                Comm* c = comm_of(h);
-                if (int rc = pcl_internal::make_current(h)) return rc;
-                PCL_NCCL_TRY(g_rccl.AllGather(c->d_pair_send, c->d_pair_recv, cap * 4, ncclFloat, c->comm,
-                                              pcl_internal::stream_of(h)));
+            {
+                GroupScope group;
+                if (int rc = group.begin(s.n > 1)) return rc;
+                for (int i = 0; i < s.n; ++i) {
+                    pcl_compute* h = s.h[i];
+                    Comm* c = comm_of(h);
+                    if (int rc = pcl_internal::make_current(h)) return rc;
+                    PCL_NCCL_TRY(g_rccl.AllGather(c->d_pair_send, c->d_pair_recv, cap * 4, ncclFloat, c->comm,
+                                                  pcl_internal::stream_of(h)));
+                }
+                if (int rc = group.end()) return rc;
             }
-            if (int rc = group_end(s)) return rc;
             for (int i = 0; i < s.n; ++i)
                 if (int rc = pcl_step_pairs_gathered(s.h[i], comm_of(s.h[i])->d_pair_recv, cap * world)) return rc;
         }
@@ -513,6 +566,15 @@ int pcl_comm_world(const pcl_compute* h)
 {
     const Comm* c = h ? static_cast<const Comm*>(pcl_internal::comm_of(h)) : nullptr;
     return c ? c->world : 0;
+}
+
+int pcl_comm_count(const pcl_compute* h)
+{
+    const Comm* c = h ? static_cast<const Comm*>(pcl_internal::comm_of(h)) : nullptr;
+    if (!c || !c->comm || !g_rccl.CommCount) return 0;
+    int count = 0;
+    if (g_rccl.CommCount(c->comm, &count) != ncclSuccess) return -1;
+    return count;
 }
 
 int pcl_comm_update_force_grid(pcl_compute* h, const float (*force_grid)[4], size_t n_cells, int root)

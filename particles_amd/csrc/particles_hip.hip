@@ -2164,6 +2164,14 @@ int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks, uint32_t* b
     return PCL_OK;
 }
 
+int pcl_device_pci_bus_id(const pcl_compute* h, char* out, size_t capacity)
+{
+    if (!h) return fail(PCL_ERR_INVALID, "null handle");
+    PCL_REQUIRE(out != nullptr && capacity >= 16, "pcl_device_pci_bus_id: output buffer of at least 16 bytes");
+    PCL_HIP_TRY(hipDeviceGetPCIBusId(out, (int)std::min<size_t>(capacity, 64), h->device));
+    return PCL_OK;
+}
+
 int pcl_launch_residency(const pcl_compute* h, uint32_t* intended_blocks_per_cu, uint32_t* granted_blocks_per_cu)
 {
     if (!h) return fail(PCL_ERR_INVALID, "null handle");

@@ -283,6 +283,13 @@ ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist)
     return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count)
+{
+    if (!comm || !count) return ncclInvalidArgument;
+    *count = comm->team->world;
+    return ncclSuccess;
+}
+
 ncclResult_t ncclCommDestroy(ncclComm_t comm)
 {
     if (!comm) return ncclSuccess;
