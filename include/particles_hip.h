@@ -357,6 +357,17 @@ int pcl_diagnostics_device_noalloc(pcl_compute* h, void* dev_out);
  * (src/compute.wgsl:81-89,147), for bit-exact index tests. */
 int pcl_debug_cell_indices(pcl_compute* h, uint32_t* out, size_t first, size_t count);
 
+/* Test hook for the bin work of the cell-binned pair term (no counterpart in the
+ * reference, whose loop of src/compute.wgsl:115-144 visits every particle): runs
+ * the sort by cut-off cell that the binned step runs before its sweep and returns,
+ * in caller order, the cell key of every particle ((cx * n + cy) * n + cz for n
+ * cells per axis) and, when bin_end is not null, for every cell one past the last
+ * slot of the sorted order that holds one of its particles (n^3 entries;
+ * bin_capacity is the room in bin_end).  The particles are left in cell order;
+ * results of later steps and reads are unaffected. */
+int pcl_debug_pair_cells(pcl_compute* h, uint32_t* cell_of_particle, uint32_t* bin_end, size_t bin_capacity,
+                         uint32_t* cells_per_axis, uint32_t* reach);
+
 /* Run subsequent work of this handle on `hip_stream` (a hipStream_t owned by
  * the caller, e.g. torch's current stream); NULL restores the internal one. */
 int pcl_set_stream(pcl_compute* h, void* hip_stream);

@@ -61,6 +61,9 @@ def load():
     lib.orc_run.argtypes = [vp, vp, vp, sz, vp, sz, i, i, i]
     lib.orc_max_threads.restype = i
     lib.orc_cell_indices.argtypes = [vp, vp, sz, sz, vp]
+    lib.orc_pair_term_magnitudes.argtypes = [vp, vp, sz, sz, sz, vp, vp]
+    lib.orc_pair_cell_map.argtypes = [vp, i, u32, vp, vp, vp]
+    lib.orc_pair_cell_keys.argtypes = [vp, vp, sz, u32, f, vp]
     lib.orc_diagnostics_of.argtypes = [vp, vp, sz, C.POINTER(Diagnostics)]
     lib.orc_lattice_particles.argtypes = [vp, f, f, f, sz, sz, sz]
     lib.orc_grid_centered.argtypes = [vp, sz, sz, sz]
@@ -169,6 +172,31 @@ def cell_indices(params, particles, n_cells):
     out = np.zeros(src.shape[0], dtype=np.uint32)
     load().orc_cell_indices(_p(_params_buf(params)), _p(src), src.shape[0], int(n_cells), _p(out))
     return out
+
+
+def pair_term_magnitudes(params, particles, first=0, count=None):
+    """Per particle of [first, first + count): sum of |pair term| per component (float64, shape (count, 3))
+    and the number of terms the skip tests let through (what bounds the effect of the summation order)."""
+    p = _particles(particles)
+    count = p.shape[0] - first if count is None else count
+    abs_sum = np.zeros((count, 3), dtype=np.float64)
+    terms = np.zeros(count, dtype=np.uint32)
+    load().orc_pair_term_magnitudes(_p(_params_buf(params)), _p(p), p.shape[0], first, count, _p(abs_sum), _p(terms))
+    return abs_sum, terms
+
+
+def pair_cell_map(params, allow_reach2=True, max_axis=20):
+    """(cells per axis, reach, inv_cell) of the cut-off cells the library bins the pair term by."""
+    n, r, inv = C.c_uint32(), C.c_uint32(), C.c_float()
+    load().orc_pair_cell_map(_p(_params_buf(params)), int(allow_reach2), int(max_axis), C.byref(n), C.byref(r), C.byref(inv))
+    return n.value, r.value, np.float32(inv.value)
+
+
+def pair_cell_keys(params, particles, cells_per_axis, inv_cell):
+    p = _particles(particles)
+    keys = np.zeros(p.shape[0], dtype=np.uint32)
+    load().orc_pair_cell_keys(_p(_params_buf(params)), _p(p), p.shape[0], int(cells_per_axis), float(inv_cell), _p(keys))
+    return keys
 
 
 def diagnostics(params, particles):

@@ -270,6 +270,88 @@ static void step_one(const orc_sim_params* params, const orc_particle* src,
     dst[index] = out;
 }
 
+/* What bounds the effect of the ORDER in which a particle's pair terms are added (the cell-binned
+ * kernel of the library adds them cell by cell, src/compute.wgsl:115-144 in index order): for
+ * particles [first, first + count), per component the sum of the terms' magnitudes (in double) and the
+ * number of terms that passed the skip tests of wgsl:126-131.  Recursive fp32 summation of m terms in
+ * any order stays within (m - 1) * 2^-24 * sum|t| of the exact sum. */
+void orc_pair_term_magnitudes(const orc_sim_params* params, const orc_particle* src, size_t total,
+                              size_t first, size_t count, double (*abs_sum)[3], uint32_t* terms)
+{
+    for (size_t k = 0; k < count; ++k) {
+        const size_t index = first + k;
+        const float vPos[3] = { src[index].pos[0], src[index].pos[1], src[index].pos[2] };
+        const uint32_t vParticleType = src[index].ty;
+        double acc[3] = { 0.0, 0.0, 0.0 };
+        uint32_t m = 0;
+        for (size_t i = 0; i < total; ++i) {
+            if (i == index) continue;
+            float direction[3] = { src[i].pos[0] - vPos[0], src[i].pos[1] - vPos[1], src[i].pos[2] - vPos[2] };
+            const float direction_length = length3(direction);
+            if (direction_length < 0.001f) continue;
+            if (direction_length > params->cut_off_distance) continue;
+            const float distance_factor = powf(direction_length, params->distance_exponent);
+            const float len = length3(direction);
+            const float m2 = params->particle_type_masses[src[i].ty].mass;
+            const float pv = orc_eval_poly7(direction_length,
+                                            params->attraction_force[src[i].ty + vParticleType * 5u].coeffs);
+            for (int c = 0; c < 3; ++c) {
+                float t = (direction[c] / len) * pv;
+                t = t * m2;
+                t = t * distance_factor;
+                acc[c] += fabs((double)t);
+            }
+            ++m;
+        }
+        abs_sum[k][0] = acc[0]; abs_sum[k][1] = acc[1]; abs_sum[k][2] = acc[2];
+        terms[k] = m;
+    }
+}
+
+/* ---- cut-off cells of the library's cell-binned pair term -------------------------------------
+ * No counterpart in the reference (its loop visits every particle); restated here because the
+ * cells are index work that must match bit for bit.  The library sorts the particles by a uniform
+ * grid of n x n x n cells over the bounding volume whose edge is at least 1.0001 x the cut-off
+ * (swept one cell each way), or at least half of that (swept two cells each way) where that sweeps
+ * the smaller volume; n is capped (20, or 64 for large sets).  A particle's cell along an axis is
+ * u32((clamp(p, -slh, slh) - (-slh)) * inv_cell) clamped to n - 1, with inv_cell = (float)(n / side),
+ * and its key (cx * n + cy) * n + cz. */
+void orc_pair_cell_map(const orc_sim_params* p, int allow_reach2, uint32_t max_axis,
+                       uint32_t* cells_per_axis, uint32_t* reach, float* inv_cell)
+{
+    const double side = 2.0 * (double)p->bounding_volume_radius;
+    const double edge = (double)p->cut_off_distance * 1.0001;
+    uint32_t n = 1, r = 1;
+    if (side > 0.0 && edge > 0.0 && isfinite(side) && isfinite(edge)) {
+        const double cap = (double)max_axis;
+        const double n1 = fmin(cap, fmax(1.0, floor(side / edge)));
+        const double n2 = fmin(cap, fmax(1.0, floor(2.0 * side / edge)));
+        if (allow_reach2 && 5.0 / n2 < 3.0 / n1) { n = (uint32_t)n2; r = 2; }
+        else { n = (uint32_t)n1; r = 1; }
+    }
+    *cells_per_axis = n;
+    *reach = r;
+    *inv_cell = (side > 0.0 && isfinite(side)) ? (float)((double)n / side) : 0.0f;
+}
+
+void orc_pair_cell_keys(const orc_sim_params* p, const orc_particle* particles, size_t count,
+                        uint32_t cells_per_axis, float inv_cell, uint32_t* keys)
+{
+    const float side = p->bounding_volume_radius * 2.0f;
+    const float slh = side * 0.5f, neg_slh = -slh;
+    const uint32_t last = cells_per_axis - 1u;
+    for (size_t k = 0; k < count; ++k) {
+        uint32_t c[3];
+        for (int a = 0; a < 3; ++a) {
+            const float v = fminf(fmaxf(particles[k].pos[a], neg_slh), slh);
+            const float t = (v - neg_slh) * inv_cell;
+            uint32_t i = to_u32(t);
+            c[a] = i < last ? i : last;
+        }
+        keys[k] = (c[0] * cells_per_axis + c[1]) * cells_per_axis + c[2];
+    }
+}
+
 /*
  * Update particles [first, first+count) of a set of `total`.  `mode`:
  * 0 = always run the pair loop, as the shader does;

@@ -307,6 +307,17 @@ class Compute:
         _lib.check(self._lib.pcl_debug_cell_indices(self._h, _ptr(out), int(first), int(count)))
         return out
 
+    def debug_pair_cells(self):
+        """Cut-off cells of the binned pair term: (cell key per particle in caller order, bin_end per cell,
+        cells per axis, reach)."""
+        n = self.num_particles
+        cells = np.zeros(n, dtype=np.uint32)
+        bin_end = np.zeros(64 ** 3, dtype=np.uint32)
+        per_axis, reach = C.c_uint32(), C.c_uint32()
+        _lib.check(self._lib.pcl_debug_pair_cells(self._h, _ptr(cells), _ptr(bin_end), bin_end.shape[0],
+                                                  C.byref(per_axis), C.byref(reach)))
+        return cells, bin_end[: per_axis.value ** 3], per_axis.value, reach.value
+
     def set_pair_mode(self, mode):
         """0 automatic, 1 all-pairs sweep in index order (bit-exact), 2 cell-binned."""
         _lib.check(self._lib.pcl_set_pair_mode(self._h, int(mode)))

@@ -985,6 +985,14 @@ pcl::TileMap make_pair_cell_map(const pcl_sim_params& p, bool allow_reach2 = tru
     return C;
 }
 
+// The cut-off cells the binned pair step of this handle sorts by
+// (tuning bits: 0x10000 one-cell reach only, 0x20000 at most 20 cells per axis).
+pcl::TileMap pair_cell_map_of(const pcl_compute* h)
+{
+    return make_pair_cell_map(h->params, (h->variant & 0x10000u) == 0,
+                              ((h->variant & 0x20000u) || h->n < kPairWideMinParticles) ? 20u : kPairMaxCellsPerAxis);
+}
+
 bool use_binned_pairs(const pcl_compute* h)
 {
     if (h->pair_mode == PCL_PAIRS_ALL) return false;
@@ -1179,9 +1187,7 @@ int do_step_impl(pcl_compute* h, int* kind)
             PCL_HIP_TRY(hipStreamSynchronize(h->stream));
             h->params_dirty = false;
         }
-        // tuning bits: 0x10000 one-cell reach only, 0x20000 at most 20 cells per axis
-        const pcl::TileMap C = make_pair_cell_map(h->params, (h->variant & 0x10000u) == 0,
-                                                  ((h->variant & 0x20000u) || h->n < kPairWideMinParticles) ? 20u : kPairMaxCellsPerAxis);
+        const pcl::TileMap C = pair_cell_map_of(h);
         const uint32_t* bin_end = nullptr;   // bin_end[b]: one past the last slot of cell b
         if (int rc = cell_sort(h, U, C, &bin_end)) return rc;
         const size_t blocks = (h->n + pcl::kBlockThreads - 1) / pcl::kBlockThreads;
@@ -2075,6 +2081,35 @@ int pcl_debug_cell_indices(pcl_compute* h, uint32_t* out, size_t first, size_t c
     (void)hipFree(d);
     if (e != hipSuccess) return fail(PCL_ERR_HIP, std::string("pcl_debug_cell_indices: ") + hipGetErrorString(e));
     return sync_stream(h);
+}
+
+int pcl_debug_pair_cells(pcl_compute* h, uint32_t* cell_of_particle, uint32_t* bin_end, size_t bin_capacity,
+                         uint32_t* cells_per_axis, uint32_t* reach)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_REQUIRE(cells_per_axis && reach, "pcl_debug_pair_cells: null output");
+    PCL_REQUIRE(h->n >= 1 && h->n <= 0x7FFFFFFFull, "pcl_debug_pair_cells: 1 .. 2^31 - 1 particles");
+    const pcl::TileMap C = pair_cell_map_of(h);
+    *cells_per_axis = C.nty;
+    *reach = C.reach;
+    PCL_REQUIRE(!bin_end || bin_capacity >= C.n_bins, "pcl_debug_pair_cells: bin_end is too small");
+    // exactly the sort the binned pair step runs before its sweep (the particles end up in cell order)
+    const uint32_t* d_bin_end = nullptr;
+    if (int rc = cell_sort(h, uniforms_of(h), C, &d_bin_end)) return rc;
+    if (bin_end)
+        PCL_HIP_TRY(hipMemcpyAsync(bin_end, d_bin_end, (size_t)C.n_bins * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    std::vector<uint32_t> key(h->n), caller(h->n);
+    const uint32_t* key_out = h->d_cellsort + h->cellsort_capacity;          // sorted keys, slot by slot
+    const uint32_t* idx_out = h->d_cellsort + 3 * h->cellsort_capacity;      // caller index of every slot
+    PCL_HIP_TRY(hipMemcpyAsync(key.data(), key_out, h->n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    PCL_HIP_TRY(hipMemcpyAsync(caller.data(), idx_out, h->n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    if (int rc = sync_stream(h)) return rc;
+    if (cell_of_particle)
+        for (size_t slot = 0; slot < h->n; ++slot) {
+            PCL_REQUIRE(caller[slot] < h->n, "pcl_debug_pair_cells: the sort returned an index outside the set");
+            cell_of_particle[caller[slot]] = key[slot];
+        }
+    return PCL_OK;
 }
 
 int pcl_set_stream(pcl_compute* h, void* hip_stream)
