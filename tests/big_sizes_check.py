@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Maximum-size check (run by hand on the GPU box: ``python tests/big_sizes_check.py 30 31``):
-2^k particles generated on the device, 1024^2 field, automatic tile order, 18 steps (one full
-count + scatter refresh cycle); slices of the result against the oracle stepping the same global
+2^k particles generated on the device, 1024^2 field, automatic tile order, 26 steps (one full
+count + scatter refresh cycle at the interval of 24); slices of the result against the oracle stepping the same global
 indices.  Arrays of 2^30 floats and more put byte offsets beyond 32 bits."""
 import os
 import sys
@@ -17,7 +17,7 @@ from conftest import assert_particles_bit_equal, scene_swirl_field
 from oracle import oracle as O
 
 
-def check(sizes, steps=18):
+def check(sizes, steps=26):
     sp = pa.SimParams()
     sp.delta_t = np.float32(1.0 / 60.0)
     sp.force_grid_dimensions = (1024, 1024, 1)
@@ -46,7 +46,7 @@ def check(sizes, steps=18):
 if __name__ == "__main__":
     # usage: big_sizes_check.py [--steps K] log2n...
     argv = sys.argv[1:]
-    k = 18
+    k = 26
     if argv and argv[0] == "--steps":
         k = int(argv[1])
         argv = argv[2:]

@@ -309,27 +309,84 @@ def test_pair_kernel_after_reorder_runs_in_caller_order(oracle):
         assert_particles_bit_equal(c.read_particles(), oracle.run(sp2, mid, g, 1), "pairs after tile order")
 
 
-def test_full_size_slices_match_oracle(oracle):
-    """2^26 particles generated on the device, 1024^2 field, automatic tile
-    order: particles are independent, so slices of the big run are checked
-    against the oracle stepping the same global indices."""
+@pytest.mark.parametrize("log2n", [26, 28])
+def test_full_size_slices_match_oracle(oracle, log2n):
+    """2^26 and 2^28 particles (2^28 on this field is BASELINE configuration 3, the workload the
+    bandwidth target is quoted on) generated on the device, 1024^2 field, everything automatic: the
+    default launch shape (256-thread blocks, three per CU), the tile order refreshed every 24 steps,
+    52 steps = two whole refresh cycles after the first sort.  Particles are independent, so slices
+    of the big run are checked against the oracle stepping the same global indices."""
     sp = pa.SimParams()
     sp.delta_t = DT
     sp.force_grid_dimensions = (1024, 1024, 1)
     sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
     g = scene_swirl_field(1024, 1024, 1, 10.0, seed=5)
-    n = 1 << 26
+    n = 1 << log2n
+    steps = 52
     with pa.Compute.new(pa.empty_particles(0), g) as c:
         c.update_sim_params(sp)
         c.generate_particles(n, seed=2025, pos_extent=20.0, vel_extent=10.0)
-        for _ in range(20):
+        assert c.reorder_interval_in_use == 24
+        for _ in range(steps):
             c.compute()
-        assert c.reorder_count >= 2          # automatic: field > 64 KiB, n >= 2^20
-        for first in (0, 12345678, n - 4000):
+        assert c.reorder_count >= 4          # the first sort in two passes, then one refresh per cycle
+        assert c.launch_geometry()["block_threads"] == 256
+        assert c.launch_residency() == {"intended": 3, "granted": 3}
+        for first in (0, 12345678, n // 2 - 2000, n - 4000):
             p = oracle.synth_particles(4000, seed=2025, first_global_index=first, pos_extent=20.0, vel_extent=10.0)
-            want = oracle.run(sp, p, g, 20, mode=oracle.MODE_SKIP_INERT)
-            assert_particles_bit_equal(c.read_particles(first, 4000), want, f"slice at {first}")
+            want = oracle.run(sp, p, g, steps, mode=oracle.MODE_SKIP_INERT)
+            assert_particles_bit_equal(c.read_particles(first, 4000), want, f"2^{log2n} slice at {first}")
+            assert np.array_equal(c.debug_cell_indices(first, 4000), oracle.cell_indices(sp, want, g.shape[0]))
         assert c.diagnostics()["count"] == n
+
+
+def test_config4_share_with_diagnostics_every_step_through_the_library_communicator(oracle):
+    """One GPU's share of BASELINE configuration 4 (2^30 particles over 8 GPUs = 2^27 each, 1024^2 field,
+    diagnostics all-reduced every step), stepped through pcl_comm_step on a one-rank RCCL communicator
+    attached to the handle: after every step the all-reduced record against the oracle's over ALL 2^27
+    particles (count and bounds exact, kinetic energy to 1e-11: f64 sums of 1.3e8 terms in different orders), at the end slices bit for bit.  Ten
+    steps at a refresh interval of 4, so that the plain, the counting and the scatter step with fused
+    diagnostics all run at this size."""
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = (1024, 1024, 1)
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    g = scene_swirl_field(1024, 1024, 1, 10.0, seed=5)
+    n = 1 << 27
+    steps = 10
+    # the oracle's diagnostics of every step, chunk by chunk (particles are independent; sums in f64)
+    chunk = 1 << 22
+    threads = max(1, min(oracle.max_threads(), 16))
+    ke = np.zeros(steps)
+    mx = np.full((steps, 3), -np.inf, dtype=np.float32)
+    mn = np.full((steps, 3), np.inf, dtype=np.float32)
+    for first in range(0, n, chunk):
+        p = oracle.synth_particles(chunk, seed=77, first_global_index=first, pos_extent=20.0, vel_extent=10.0)
+        for k in range(steps):
+            p = oracle.step(sp, p, g, mode=oracle.MODE_SKIP_INERT, threads=threads)
+            d = oracle.diagnostics(sp, p)
+            ke[k] += d["kinetic_energy"]
+            mx[k] = np.maximum(mx[k], d["pos_max"])
+            mn[k] = np.minimum(mn[k], d["pos_min"])
+    with pa.Compute.new(pa.empty_particles(0), np.zeros((1, 4), dtype=np.float32)) as c:
+        c.comm_attach(pa.Compute.comm_unique_id(), 0, 1)
+        assert c.comm_count == 1
+        c.comm_update_force_grid(g, g.shape[0])
+        c.update_sim_params(sp)
+        c.generate_particles(n, seed=77, pos_extent=20.0, vel_extent=10.0)
+        c.set_reorder_interval(4)
+        c.enable_step_diagnostics(True)
+        for k in range(steps):
+            c.comm_step()
+            d = c.comm_diagnostics()
+            assert d["count"] == n, f"step {k + 1}"
+            assert abs(d["kinetic_energy"] - ke[k]) <= 1e-11 * ke[k], f"step {k + 1}: {d['kinetic_energy']} vs {ke[k]}"
+            assert np.array_equal(d["pos_max"], mx[k]) and np.array_equal(d["pos_min"], mn[k]), f"step {k + 1}"
+        assert c.reorder_count >= 3
+        for first in (0, n // 2 - 1000, n - 3000):
+            p = oracle.synth_particles(3000, seed=77, first_global_index=first, pos_extent=20.0, vel_extent=10.0)
+            want = oracle.run(sp, p, g, steps, mode=oracle.MODE_SKIP_INERT)
+            assert_particles_bit_equal(c.read_particles(first, 3000), want, f"slice at {first}")
 
 
 def test_one_billion_particles_slices_match_oracle(oracle):
