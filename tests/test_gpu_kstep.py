@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import particles_amd as pa
-from conftest import compare_k_steps, straddlers_on_trajectory
+from conftest import binned_single_step_check, compare_k_steps, straddlers_on_trajectory
 
 pytestmark = pytest.mark.gpu
 
@@ -70,6 +70,30 @@ def test_binned_pair_kernel_16_steps(oracle, exponent, cutoff, n, scale, budget_
     got = run_hip(sp, p, g, pa.PAIRS_BINNED)
     compare_k_steps(got, want, 2.0 * float(sp.bounding_volume_radius), direct, tainted, budget=n // budget_div,
                     what=f"binned pair kernel, exponent {exponent}, cut-off {cutoff}, {K} steps")
+
+
+@pytest.mark.parametrize("exponent,cutoff,n,scale", [(0.0, 1.5, 6000, 0.05), (0.5, 1.0, 6000, 0.05), (0.0, 2.5, 4000, 0.0015),
+                                                     (0.0, 2.5, 4000, 0.05)])
+def test_binned_pair_kernel_16_steps_each_checked_from_the_state_it_started_from(oracle, exponent, cutoff, n, scale):
+    """The 16 steps without the amplification of a chaotic trajectory and therefore without a budget:
+    after every step the device's state is read back, the oracle makes the same one step from the state
+    the device started that step from, and the two must agree to the vector bar of
+    binned_single_step_check with no particle outside it (the strongly forced fourth case included,
+    which the end-to-end comparison above cannot hold)."""
+    sp = gentle_pair_params(exponent, cutoff, scale)
+    g = sp.new_force_grid_centered().get_force_vectors()
+    p = oracle.synth_particles(n, seed=n + 1, pos_extent=20.0, vel_extent=10.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        c.set_pair_mode(pa.PAIRS_BINNED)
+        before = c.read_particles()
+        for k in range(K):
+            c.compute()
+            assert c.last_step_kernel == pa.KERNEL_PAIRS
+            after = c.read_particles()
+            want = oracle.step(sp, before, g, mode=oracle.MODE_ALWAYS_PAIRS)
+            binned_single_step_check(oracle, sp, before, g, after, want, 0, f"step {k + 1} of {K}, exponent {exponent}, cut-off {cutoff}")
+            before = after
 
 
 def test_binned_pair_kernel_is_reproducible_run_to_run(oracle):

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import particles_amd as pa
-from conftest import assert_particles_bit_equal, scene_swirl_field
+from conftest import assert_particles_bit_equal, scene_swirl_field, binned_single_step_check
 
 pytestmark = pytest.mark.gpu
 
@@ -510,42 +510,6 @@ def _close(got, want, two_r, rtol=1e-5, atol=1e-6):
         assert not bad.any(), f"{f}: {bad.sum()} components out of tolerance, worst {d.max()}"
 
 
-def _binned_single_step_check(oracle, sp, p_all, g, got, want, first, what):
-    """One step of the binned kernel against the oracle.  Every pair term is computed exactly as the
-    oracle computes it; what differs is the order in which a particle's terms are added.  The bar is on
-    the VECTORS, per particle and with no allowance:
-        |dv| <= 1e-5 max(|v_got|, |v_want|) + 1e-6
-        |dx| <= 1e-5 max(|x_got|, |x_want|) + 1e-6,   x modulo 2r per axis
-    (a per-component bar fails for small components of a velocity that the speed clamp of wgsl:157-160
-    holds at max_velocity: a reordered sum moves the direction of a long vector by eps of its length).
-    For information the number of terms per particle and the size of the summation-order effect
-    (2 (m - 1) 2^-24 sum|t| per component, from the oracle's own loop) are printed."""
-    from conftest import RTOL, ATOL
-    two_r = 2.0 * float(sp.bounding_volume_radius)
-    n = got.shape[0]
-    abs_sum, terms = oracle.pair_term_magnitudes(sp, p_all, first, n)
-    da = 2.0 * np.maximum(terms.astype(np.float64) - 1.0, 0.0)[:, None] * 2.0 ** -24 * abs_sum
-
-    def vec(f):
-        a, b = got[f][:, :3].astype(np.float64), want[f][:, :3].astype(np.float64)
-        d = np.abs(a - b)
-        if f == "pos":
-            d = np.minimum(d, np.abs(two_r - d))       # modulo the wrap
-        return np.linalg.norm(d, axis=1), np.maximum(np.linalg.norm(a, axis=1), np.linalg.norm(b, axis=1))
-
-    dv, vmax = vec("vel")
-    dx, xmax = vec("pos")
-    print(f"[binned, one step] {what}: worst |dv| / bar {np.max(dv / (RTOL * vmax + ATOL)):.3g}, worst |dx| / bar "
-          f"{np.max(dx / (RTOL * xmax + ATOL)):.3g}; up to {int(terms.max())} terms per particle, bound on the "
-          f"acceleration's summation-order difference up to {np.linalg.norm(da, axis=1).max():.3g}")
-    bad_v, bad_x = np.nonzero(dv > RTOL * vmax + ATOL)[0], np.nonzero(dx > RTOL * xmax + ATOL)[0]
-    assert bad_v.size == 0, (f"{what}: {bad_v.size} velocities beyond 1e-5 max|v| + 1e-6; first {first + bad_v[0]}: "
-                             f"|dv| {dv[bad_v[0]]:.3g} against |v| {vmax[bad_v[0]]:.3g}")
-    assert bad_x.size == 0, (f"{what}: {bad_x.size} positions beyond 1e-5 max|x| + 1e-6; first {first + bad_x[0]}: "
-                             f"|dx| {dx[bad_x[0]]:.3g} against |x| {xmax[bad_x[0]]:.3g}")
-    assert np.array_equal(got["ty"], want["ty"])
-
-
 @pytest.mark.parametrize("n,cutoff,extent,max_axis", [
     (5000, 1.5, 20.0, 20),        # one-cell reach, 13 cells per axis
     (5000, 2.5, 44.0, 20),        # two-cell reach (16 cells of half the cut-off), particles beyond the box
@@ -604,7 +568,7 @@ def test_binned_pair_kernel_matches_oracle(oracle, n, cutoff, extent, exponent):
         got = c.read_particles()
         assert c.last_step_kernel == pa.KERNEL_PAIRS
     want = oracle.run(sp, p, g, 1)
-    _binned_single_step_check(oracle, sp, p, g, got, want, 0, f"n={n} cut-off {cutoff} extent {extent} exponent {exponent}")
+    binned_single_step_check(oracle, sp, p, g, got, want, 0, f"n={n} cut-off {cutoff} extent {extent} exponent {exponent}")
 
 
 def test_binned_pairs_many_cells_sorted_with_global_counters(oracle):
@@ -622,8 +586,8 @@ def test_binned_pairs_many_cells_sorted_with_global_counters(oracle):
         c.compute()                              # automatic mode: binned, 64^3 cells, two-cell reach
         assert c.last_step_kernel == pa.KERNEL_PAIRS
         got = np.concatenate([c.read_particles(0, 300), c.read_particles(n - 300, 300)])
-    _binned_single_step_check(oracle, sp, p, g, got[:300], oracle.step_range(sp, p, g, 0, 300), 0, "2^18, first 300")
-    _binned_single_step_check(oracle, sp, p, g, got[300:], oracle.step_range(sp, p, g, n - 300, 300), n - 300, "2^18, last 300")
+    binned_single_step_check(oracle, sp, p, g, got[:300], oracle.step_range(sp, p, g, 0, 300), 0, "2^18, first 300")
+    binned_single_step_check(oracle, sp, p, g, got[300:], oracle.step_range(sp, p, g, n - 300, 300), n - 300, "2^18, last 300")
 
 
 def test_binned_and_exact_pair_kernels_agree_over_steps(oracle):
