@@ -464,7 +464,8 @@ int pcl_launch_residency(const pcl_compute* h, uint32_t* intended_blocks_per_cu,
  *   0x80000  the streaming step updates the particle arrays in place instead of ping-pong
  *   0xF000000  resident blocks per CU of the plain streaming step (1-12; 15 = as many as fit), and
  *   0x70000000 its block size (0: 512 threads, 1: 256, 2: 128, 3: 64); both zero = automatic
- *            (256 threads, 3 blocks per CU from 2^23 particles on, 4 with fused diagnostics; 512 threads, as many as fit below)
+ *            (256 threads, 3 blocks per CU from 2^23 particles on; with fused diagnostics 4, or 512 threads x 3 when the
+ *            field exceeds 4 MiB; 512 threads, as many as fit below)
  *   0x300000 resident blocks per CU of the counting step (1-3; 0 = automatic)
  *   0x4      the scalar path of the streaming kernels only (full divisions) instead of the packed one
  *   0x200    particles in caller order are sorted once instead of twice before their first step

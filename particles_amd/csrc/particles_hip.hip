@@ -608,8 +608,9 @@ struct PlainShape {
 // 256 threads x 3 per CU (12 waves) 2.20 ms, x 2: 2.21, x 4: 2.34, x 5: 2.32; 128 x 4: 2.23; 512 x 2: 2.36;
 // 512 x 3 (what the registers allow): 2.36.  The same order from 2^20 particles up on that field (2^24: 0.147
 // against 0.169 ms uncapped) and from 2^23 up on a 256^2 field (2^22: 0.0424 capped against 0.0401).
-// With fused diagnostics (80 registers, a block-level fold at the end) four blocks: 2^27 particles
-// 1.155 ms against 1.209 uncapped and 1.338 at three.  On the scalar path (operands outside the packed
+// With fused diagnostics (80 registers, a block-level fold at the end) the block count per particle matters:
+// on a field beyond the L2's reach (1024^2) 512 threads x 3 per CU (2^27 particles: 1.157 ms against 1.200 at
+// 256 x 4, 1.26 uncapped), on a 256^2 field 256 x 4 (2^26: 0.557 against 0.568 ms).  On the scalar path (operands outside the packed
 // path's window) the arithmetic is twice as long and five blocks were the optimum (2.28 against 2.34 ms).
 PlainShape plain_shape(const pcl_compute* h, bool diag, bool packed)
 {
@@ -619,7 +620,8 @@ PlainShape plain_shape(const pcl_compute* h, bool diag, bool packed)
     const bool large = h->n >= ((size_t)1 << 23) || (h->n >= ((size_t)1 << 20) && field_bytes > ((size_t)4 << 20));
     if (!large) return PlainShape{(uint32_t)pcl::kStreamThreads, 0u};
     if (!packed) return (diag || h->n < ((size_t)3 << 24)) ? PlainShape{(uint32_t)pcl::kStreamThreads, 0u} : PlainShape{256u, 5u};
-    return PlainShape{256u, diag ? 4u : 3u};
+    if (diag) return field_bytes > ((size_t)4 << 20) ? PlainShape{512u, 3u} : PlainShape{256u, 4u};
+    return PlainShape{256u, 3u};
 }
 
 // Resident blocks per CU of the counting step (512 threads; 0: whatever fits).  2^28 particles: 2.46 ms at

@@ -365,39 +365,47 @@ struct DiagAcc {
     }
 };
 
-__device__ __forceinline__ double shfl_down_f64(double v, int delta)
+// Wave-wide reductions on the data-parallel-primitive path of the VALU (no LDS traffic): an inclusive
+// scan inside each row of 16 lanes (row_shr 1, 2, 4, 8), then the row totals handed on with row_bcast:15
+// (into rows 1 and 3) and row_bcast:31 (into rows 2 and 3); lane 63 ends up with the reduction over the
+// wave.  Lanes without a source lane take `identity`.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_take(uint32_t identity, uint32_t v)
 {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __shfl_down(lo, delta, 64);
-    hi = __shfl_down(hi, delta, 64);
-    return __hiloint2double(hi, lo);
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
 }
 
-__device__ __forceinline__ unsigned long long shfl_down_u64(unsigned long long v, int delta)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void diag_dpp_step(DiagAcc& acc)
 {
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    lo = __shfl_down(lo, delta, 64);
-    hi = __shfl_down(hi, delta, 64);
-    return ((unsigned long long)hi << 32) | lo;
+    const uint32_t ninf = 0xFF800000u;   // -inf
+    const unsigned long long ke_bits = __builtin_bit_cast(unsigned long long, acc.ke);
+    const uint32_t ke_lo = dpp_take<CTRL, ROW_MASK>(0u, (uint32_t)ke_bits), ke_hi = dpp_take<CTRL, ROW_MASK>(0u, (uint32_t)(ke_bits >> 32));
+    acc.ke += __builtin_bit_cast(double, ((unsigned long long)ke_hi << 32) | ke_lo);
+    const uint32_t c_lo = dpp_take<CTRL, ROW_MASK>(0u, (uint32_t)acc.count), c_hi = dpp_take<CTRL, ROW_MASK>(0u, (uint32_t)(acc.count >> 32));
+    acc.count += ((unsigned long long)c_hi << 32) | c_lo;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        acc.mx[c] = fmaxf(acc.mx[c], __uint_as_float(dpp_take<CTRL, ROW_MASK>(ninf, __float_as_uint(acc.mx[c]))));
+        acc.nmn[c] = fmaxf(acc.nmn[c], __uint_as_float(dpp_take<CTRL, ROW_MASK>(ninf, __float_as_uint(acc.nmn[c]))));
+    }
 }
 
 // Reduce one accumulator per thread to one DiagPartial per block, in a fixed
-// order (wave tree, then waves 0..3 in sequence): deterministic for a given
+// order (the wave's scan above, then the waves in sequence): deterministic for a given
 // launch geometry.
 template <int THREADS = kBlockThreads>
 __device__ __forceinline__ void block_reduce_store(DiagAcc acc, DiagPartial* out)
 {
     __shared__ DiagPartial wave_part[THREADS / 64];
-    for (int d = 32; d >= 1; d >>= 1) {
-        acc.ke += shfl_down_f64(acc.ke, d);
-        acc.count += shfl_down_u64(acc.count, d);
-        for (int c = 0; c < 3; ++c) {
-            acc.mx[c] = fmaxf(acc.mx[c], __shfl_down(acc.mx[c], d, 64));
-            acc.nmn[c] = fmaxf(acc.nmn[c], __shfl_down(acc.nmn[c], d, 64));
-        }
-    }
+    diag_dpp_step<0x111, 0xf>(acc);   // row_shr:1
+    diag_dpp_step<0x112, 0xf>(acc);   // row_shr:2
+    diag_dpp_step<0x114, 0xf>(acc);   // row_shr:4
+    diag_dpp_step<0x118, 0xf>(acc);   // row_shr:8
+    diag_dpp_step<0x142, 0xa>(acc);   // row_bcast:15 into rows 1 and 3
+    diag_dpp_step<0x143, 0xc>(acc);   // row_bcast:31 into rows 2 and 3
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
+    if (lane == 63) {
         DiagPartial p;
         p.kinetic_energy = acc.ke;
         p.count = acc.count;

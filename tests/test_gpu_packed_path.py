@@ -175,7 +175,8 @@ def test_residency_cap_is_what_the_runtime_grants(oracle, bsel, block, cap):
 
 
 def test_automatic_launch_shape_is_granted(oracle):
-    """The default shape of a large set (256 threads, three blocks per CU; four with fused diagnostics)."""
+    """The default shape of a large set (256 threads, three blocks per CU; with fused diagnostics four, or 512 threads
+    x three on a large field)."""
     dims = (256, 256, 1)
     sp = _params(dims)
     g = scene_swirl_field(*dims, 10.0, seed=51)
@@ -189,3 +190,18 @@ def test_automatic_launch_shape_is_granted(oracle):
         c.enable_step_diagnostics(True)
         c.compute()
         assert c.launch_residency() == {"intended": 4, "granted": 4}
+    # a field beyond the L2's reach: with fused diagnostics 512-thread blocks, three per CU
+    dims = (1024, 1024, 1)
+    sp = _params(dims)
+    g = scene_swirl_field(*dims, 10.0, seed=53)
+    with pa.Compute.new(pa.empty_particles(0), g) as c:
+        c.update_sim_params(sp)
+        c.generate_particles(1 << 23, seed=54, pos_extent=20.0, vel_extent=10.0)
+        c.enable_step_diagnostics(True)
+        for _ in range(3):
+            c.compute()
+        assert c.launch_geometry()["block_threads"] == 512
+        assert c.launch_residency() == {"intended": 3, "granted": 3}
+        want = oracle.run(sp, oracle.synth_particles(2000, seed=54, first_global_index=(1 << 22) + 17, pos_extent=20.0, vel_extent=10.0),
+                          g, 3, mode=oracle.MODE_SKIP_INERT)
+        assert_particles_bit_equal(c.read_particles((1 << 22) + 17, 2000), want, "512 x 3 with fused diagnostics")

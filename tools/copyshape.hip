@@ -159,6 +159,25 @@ __global__ __launch_bounds__(BLOCK) void deep_split_kernel(Arrays a)
     for (int k = 0; k < 3; ++k) st(a.dst[3 + k] + g, v[k]);
 }
 
+// deep, capped, on a tile-interleaved layout: the six components of TP4 consecutive groups lie next to each
+// other (component c of tile t at ((t * 6 + c) * TP4) groups), so a block reads one contiguous piece of memory
+// and writes one, instead of six pieces 1 GiB apart each
+template <int BLOCK, int TP4>
+__global__ __launch_bounds__(BLOCK) void deep_tiled_kernel(const f32x4* in, f32x4* out, unsigned long long n4)
+{
+    extern __shared__ float pad[];
+    const unsigned long long g = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= n4) return;
+    const unsigned long long base = (g / TP4) * 6ull * TP4 + (g % TP4);
+    f32x4 v[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = ld(in + base + (unsigned long long)k * TP4);
+    if (v[0].x == 12345.678f) pad[threadIdx.x] = v[1].x;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) st(out + base + (unsigned long long)k * TP4, v[k]);
+}
+
+
 int main(int argc, char** argv)
 {
     const int log2n = argc > 1 ? atoi(argv[1]) : 28;
@@ -202,6 +221,31 @@ int main(int argc, char** argv)
     };
     const unsigned long long n4 = a.n4;
     printf("n = 2^%d floats per array, 6 arrays in, 6 out (%.2f GB per pass), stagger %zu\n", log2n, bytes / 1e9, stagger);
+    if (argc > 5) {   // tile-interleaved layout against the separate arrays, same caps
+        const f32x4* in = reinterpret_cast<const f32x4*>(slab);
+        f32x4* out = reinterpret_cast<f32x4*>(slab + 6 * arr);
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&deep_capped_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&deep_tiled_kernel<256, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&deep_tiled_kernel<256, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&deep_tiled_kernel<256, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&deep_tiled_kernel<256, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        char name[96];
+        for (int round = 0; round < 2; ++round)
+            for (int bpc : {2, 3, 4, 0}) {
+                const size_t lds = bpc ? (size_t)160 * 1024 / bpc - 1024 : 0;
+                snprintf(name, sizeof name, "separate arrays, 256 threads, <= %d per CU", bpc);
+                run(name, [&] { hipLaunchKernelGGL(deep_capped_kernel<256>, dim3((unsigned)(n4 / 256)), dim3(256), lds, 0, a); });
+                snprintf(name, sizeof name, "tiles of 64 groups (one wave), <= %d per CU", bpc);
+                run(name, [&] { hipLaunchKernelGGL((deep_tiled_kernel<256, 64>), dim3((unsigned)(n4 / 256)), dim3(256), lds, 0, in, out, n4); });
+                snprintf(name, sizeof name, "tiles of 256 groups (one block), <= %d per CU", bpc);
+                run(name, [&] { hipLaunchKernelGGL((deep_tiled_kernel<256, 256>), dim3((unsigned)(n4 / 256)), dim3(256), lds, 0, in, out, n4); });
+                snprintf(name, sizeof name, "tiles of 1024 groups, <= %d per CU", bpc);
+                run(name, [&] { hipLaunchKernelGGL((deep_tiled_kernel<256, 1024>), dim3((unsigned)(n4 / 256)), dim3(256), lds, 0, in, out, n4); });
+                snprintf(name, sizeof name, "tiles of 16 groups (256 B runs), <= %d per CU", bpc);
+                run(name, [&] { hipLaunchKernelGGL((deep_tiled_kernel<256, 16>), dim3((unsigned)(n4 / 256)), dim3(256), lds, 0, in, out, n4); });
+            }
+        return 0;
+    }
     if (capped_only) {   // the two shapes the step kernel uses, for sweeps over the stagger
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&deep_capped_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         run("deep, 256-thread blocks, <= 2 per CU", [&] { hipLaunchKernelGGL(deep_capped_kernel<256>, dim3((unsigned)(n4 / 256)), dim3(256), 160 * 512 - 1024, 0, a); });
