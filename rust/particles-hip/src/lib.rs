@@ -87,6 +87,16 @@ extern "C" {
     fn pcl_group_diagnostics_read(g: *mut PclGroup, out: *mut Diagnostics) -> c_int;
     fn pcl_group_read_particles(g: *mut PclGroup, out: *mut c_void, first: usize, count: usize) -> c_int;
     fn pcl_group_synchronize(g: *mut PclGroup) -> c_int;
+
+    fn pcl_comm_unique_id(out_id: *mut c_void) -> c_int;
+    fn pcl_comm_attach(h: *mut PclCompute, unique_id: *const c_void, rank: c_int, world: c_int) -> c_int;
+    fn pcl_comm_detach(h: *mut PclCompute) -> c_int;
+    fn pcl_comm_count(h: *const PclCompute) -> c_int;
+    fn pcl_comm_update_force_grid(h: *mut PclCompute, force_grid: *const [f32; 4], n_cells: usize, root: c_int) -> c_int;
+    fn pcl_comm_step(h: *mut PclCompute) -> c_int;
+    fn pcl_comm_diagnostics_read(h: *mut PclCompute, out: *mut Diagnostics) -> c_int;
+    fn pcl_launch_residency(h: *const PclCompute, intended_blocks_per_cu: *mut u32, granted_blocks_per_cu: *mut u32) -> c_int;
+    fn pcl_device_pci_bus_id(h: *const PclCompute, out: *mut c_char, capacity: usize) -> c_int;
 }
 
 impl Poly7 {
@@ -279,6 +289,69 @@ impl Compute {
         let mut out = vec![[0.0f32; 4]; count];
         check(unsafe { pcl_read_force_grid(self.handle, out.as_mut_ptr(), first_cell, count) });
         out
+    }
+}
+
+/// Bytes of the id that rank 0 creates and every rank passes to `Compute::comm_attach`
+/// (`PCL_UNIQUE_ID_BYTES`).
+pub const UNIQUE_ID_BYTES: usize = 128;
+
+/// One process per GPU: every rank owns one `Compute` holding its index range of the particles and
+/// makes the same calls; the library talks RCCL on the handle's own stream.
+impl Compute {
+    /// The id rank 0 creates; the host carries it to the other ranks by whatever means it has.
+    pub fn comm_unique_id() -> [u8; UNIQUE_ID_BYTES] {
+        let mut id = [0u8; UNIQUE_ID_BYTES];
+        check(unsafe { pcl_comm_unique_id(id.as_mut_ptr() as *mut c_void) });
+        id
+    }
+
+    /// Joins the communicator of `world` ranks as `rank` (`ncclCommInitRank`).
+    pub fn comm_attach(&mut self, unique_id: &[u8; UNIQUE_ID_BYTES], rank: i32, world: i32) {
+        check(unsafe { pcl_comm_attach(self.handle, unique_id.as_ptr() as *const c_void, rank as c_int, world as c_int) });
+    }
+
+    pub fn comm_detach(&mut self) {
+        check(unsafe { pcl_comm_detach(self.handle) });
+    }
+
+    /// Ranks the communicator itself counts (`ncclCommCount`); 0 without a communicator.
+    pub fn comm_count(&self) -> i32 {
+        unsafe { pcl_comm_count(self.handle) }
+    }
+
+    /// `update_force_grid` on every rank: `root`'s field is broadcast into every replica (the
+    /// other ranks pass a slice of the same length, whose contents are ignored).
+    pub fn comm_update_force_grid(&mut self, force_grid: &[[f32; 4]], root: i32) {
+        check(unsafe { pcl_comm_update_force_grid(self.handle, force_grid.as_ptr(), force_grid.len(), root as c_int) });
+    }
+
+    /// `compute()` of this rank's range, with the all-gather of the pair term and the all-reduce of
+    /// the step diagnostics where those are active.
+    pub fn comm_compute(&mut self) {
+        check(unsafe { pcl_comm_step(self.handle) });
+    }
+
+    /// Diagnostics over all ranks (synchronises this rank's stream).
+    pub fn comm_diagnostics(&mut self) -> Diagnostics {
+        let mut d = Diagnostics::default();
+        check(unsafe { pcl_comm_diagnostics_read(self.handle, &mut d) });
+        d
+    }
+
+    /// Resident blocks per CU the streaming step asked for and what the runtime's occupancy
+    /// calculation grants (both 0 before the first capped launch).
+    pub fn launch_residency(&self) -> (u32, u32) {
+        let (mut intended, mut granted) = (0u32, 0u32);
+        check(unsafe { pcl_launch_residency(self.handle, &mut intended, &mut granted) });
+        (intended, granted)
+    }
+
+    /// PCI bus id of the handle's GPU ("0000:c1:00.0"), to tell devices apart across processes.
+    pub fn pci_bus_id(&self) -> String {
+        let mut buf = [0 as c_char; 32];
+        check(unsafe { pcl_device_pci_bus_id(self.handle, buf.as_mut_ptr(), buf.len()) });
+        unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned()
     }
 }
 

@@ -16,8 +16,11 @@ print(f"{sys.argv[2]:34s} {d['ms_per_step']:8.4f} ms/step {d['value']/1e9:8.2f} 
       + (f"  fused {f['ms_per_step']:.4f} ms/step" if f else ""), flush=True)
 PY
 }
-run cfg2_16M_256_uniform      --particles-per-gpu 16777216  --field 256 256 1   --pos-extent 20
-run cfg2_16M_256_cluster      --particles-per-gpu 16777216  --field 256 256 1   --pos-extent 2
+# configuration 2 steps in 0.15 ms: 100 steps end before the GPU has reached its clocks (plain kernel 0.153 ms in a
+# 100-step run, 0.143 ms from about 40 ms of work on), hence the longer run, shown beside the default length
+run cfg2_16M_256_uniform      --particles-per-gpu 16777216  --field 256 256 1   --pos-extent 20 --steps 480 --warmup 96
+run cfg2_16M_256_cluster      --particles-per-gpu 16777216  --field 256 256 1   --pos-extent 2 --steps 480 --warmup 96
+run cfg2_16M_256_uniform_100_steps --particles-per-gpu 16777216  --field 256 256 1   --pos-extent 20
 run cfg3_256M_1024_uniform    --particles-per-gpu 268435456 --field 1024 1024 1 --pos-extent 20
 run cfg3_256M_1024_cluster    --particles-per-gpu 268435456 --field 1024 1024 1 --pos-extent 2
 run cfg4_share_128M_diag      --particles-per-gpu 134217728 --field 1024 1024 1 --pos-extent 20 --diagnostics on
