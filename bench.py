@@ -174,6 +174,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch-timing", choices=("on", "off"), default="on",
                     help="off: no per-launch event pairs (the roofline then uses the whole region's time per step)")
+    ap.add_argument("--clock-warmup-ms", type=float, default=150.0,
+                    help="before the warm-up steps, keep the GPU busy for this long with a memory-bound torch kernel "
+                         "on a scratch buffer (no simulation step): a short run (20 steps of 2^25 particles are 7 ms) "
+                         "otherwise ends before the GPU has reached its clocks.  0: skip")
     ap.add_argument("--fused-steps", type=int, default=96,
                     help="after the timed region, also time this many steps through pcl_step_n (0: skip)")
     ap.add_argument("--edits", action="store_true",
@@ -302,6 +306,16 @@ def run_case(args, ctx, *, scaling, n_total, diag_on, with_cpu_baseline):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The GPU takes some tens of milliseconds of continuous work to reach its clocks; the warm-up steps of a small
+    # range are over long before that.  Untimed, touches no simulation state, advances nothing.
+    if args.clock_warmup_ms > 0:
+        scratch = torch.zeros(1 << 26, dtype=torch.float32, device=f"cuda:{device_index}")
+        t_w = time.perf_counter()
+        while (time.perf_counter() - t_w) * 1e3 < args.clock_warmup_ms:
+            for _ in range(16):
+                scratch.add_(1.0)
+            torch.cuda.synchronize()
+        del scratch
     for _ in range(args.warmup):
         one_step()
     fence()
@@ -404,6 +418,7 @@ def run_case(args, ctx, *, scaling, n_total, diag_on, with_cpu_baseline):
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "clock_warmup_ms": args.clock_warmup_ms,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": scaling,

@@ -468,6 +468,8 @@ int pcl_launch_residency(const pcl_compute* h, uint32_t* intended_blocks_per_cu,
  *            field exceeds 4 MiB; 512 threads, as many as fit below)
  *   0x300000 resident blocks per CU of the counting step (1-3; 0 = automatic)
  *   0x4      the scalar path of the streaming kernels only (full divisions) instead of the packed one
+ *   0x100    plain streaming step: runs of 128 tiles dealt so that each XCD takes 16 consecutive ones (automatic
+ *            from 3 * 2^23 to 2^26 particles in tile order with at most 40 per field cell), 0x400: never
  *   0x200    particles in caller order are sorted once instead of twice before their first step
  *   0x40000  tests only: the next refresh of the particle order scatters with other keys than its
  *            histogram counted, which the kernel reports as PCL_ERR_DEVICE (the state is then unusable) */
@@ -557,7 +559,15 @@ int pcl_comm_brush_mouse_moved(pcl_compute* h, const pcl_brush_input* in, int ro
  * particle sums over all of them in global index order, which gives the bits
  * of one handle holding every particle under PCL_PAIRS_ALL.  Step diagnostics
  * enabled: also starts the all-reduce of the record (asynchronous; the result
- * is what pcl_comm_diagnostics_device points at). */
+ * is what pcl_comm_diagnostics_device points at).  No host synchronisation,
+ * except in the first step after pcl_comm_attach, after a call that replaced
+ * the particle set (pcl_upload_particles[_soa], pcl_generate_particles) and
+ * after a change of what a step exchanges (pair term active or inert, step
+ * diagnostics on or off): that step first agrees with the other ranks on the
+ * padded range length and on these two settings (one all-reduce, read back on
+ * the host) and returns PCL_ERR_INVALID on every rank when the settings
+ * differ.  All ranks must therefore replace their particle sets and change
+ * these settings between the same two steps. */
 int pcl_comm_step(pcl_compute* h);
 /* Diagnostics of the latest state of ALL ranges, identical on every rank. */
 int pcl_comm_diagnostics_read(pcl_compute* h, pcl_diagnostics* out);

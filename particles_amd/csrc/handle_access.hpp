@@ -25,6 +25,9 @@ size_t cells_of(const pcl_compute* h);
 int diagnostics_on_device(pcl_compute* h, const void** dev_record);
 bool pair_term_active(const pcl_compute* h);              // the parameters' pair term is not provably zero
 bool step_diagnostics_enabled(const pcl_compute* h);
+// Goes up with every call that replaces the particle set (upload, SoA upload, generate), whether or
+// not the count changed: ranks that make the same calls see it change between the same two steps.
+uint64_t particles_epoch(const pcl_compute* h);
 // One slot for the multi-GPU layer's per-handle state; `release` runs in pcl_destroy.
 void set_comm(pcl_compute* h, void* comm, void (*release)(void*));
 void* comm_of(const pcl_compute* h);

@@ -14,13 +14,14 @@
 //     in f64, max of the six f32 bounds).
 // Every collective is enqueued on the handle's own stream, so it is ordered
 // with the kernels before and after it without host synchronisation.  One
-// exception: with the pair term active and one process per rank, every step
-// first agrees on the length the ranges are padded to (an all-reduce of the
-// local particle counts, read back on the host: max_local_count); a process
-// that drives the whole group knows every count and skips that.
-// All ranks must hold the same parameters: which collectives a step issues
-// follows from them (pair term active or not, step diagnostics on or off),
-// and ranks that disagree wait for each other's missing calls.
+// exception, one process per rank only: the first step after attaching, after
+// a call that replaced the particle set, and after a change of what a step
+// exchanges (pair term active or not, step diagnostics on or off) starts with
+// one all-reduce that is read back on the host (agree): the length the ranges
+// are padded to in the all-gather, and a check that the ranks are about to
+// issue the same collectives -- if not, every rank returns an error instead
+// of waiting for the others' missing calls.  Ranks must therefore replace
+// their particle sets and change these settings between the same two steps.
 //
 // Two ways to form the communicator: one process (or thread) per GPU attaches
 // its handle with a shared unique id (pcl_comm_attach: ncclCommInitRank), or
@@ -145,8 +146,12 @@ struct Comm {
     float* d_pair_send = nullptr;      // this range's 16-byte (x, y, z, type) records, padded
     float* d_pair_recv = nullptr;      // all ranges' records
     size_t pair_cap = 0;               // records per range in those buffers
-    unsigned long long* d_count = nullptr;   // all-reduce(max) of the local particle counts
-    unsigned long long* h_count = nullptr;   // pinned
+    unsigned long long* d_agree = nullptr;   // all-reduce(max) of {local count, flags}: see agree()
+    unsigned long long* h_agree = nullptr;   // pinned
+    bool agreed = false;                     // what the ranks last agreed on, and for which local state
+    uint64_t agreed_epoch = 0;
+    bool agreed_pairs = false, agreed_diag = false;
+    size_t agreed_cap = 0;
     pcl_diagnostics* d_global = nullptr;     // the all-reduced record
 };
 
@@ -161,8 +166,8 @@ void release_comm(void* p)
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_pair_send) (void)hipFree(c->d_pair_send);
     if (c->d_pair_recv) (void)hipFree(c->d_pair_recv);
-    if (c->d_count) (void)hipFree(c->d_count);
-    if (c->h_count) (void)hipHostFree(c->h_count);
+    if (c->d_agree) (void)hipFree(c->d_agree);
+    if (c->h_agree) (void)hipHostFree(c->h_agree);
     if (c->d_global) (void)hipFree(c->d_global);
     delete c;
 }
@@ -178,8 +183,8 @@ int adopt(pcl_compute* h, ncclComm_t comm, int rank, int world)
     pcl_internal::set_comm(h, c, release_comm);   // from here on pcl_destroy releases it
     if (int rc = pcl_internal::make_current(h)) return rc;
     PCL_HIP_TRY(hipMalloc(&c->d_record, sizeof(pcl_brush_input)));
-    PCL_HIP_TRY(hipMalloc((void**)&c->d_count, sizeof(unsigned long long)));
-    PCL_HIP_TRY(hipHostMalloc((void**)&c->h_count, sizeof(unsigned long long), hipHostMallocDefault));
+    PCL_HIP_TRY(hipMalloc((void**)&c->d_agree, 8 * sizeof(unsigned long long)));
+    PCL_HIP_TRY(hipHostMalloc((void**)&c->h_agree, 8 * sizeof(unsigned long long), hipHostMallocDefault));
     PCL_HIP_TRY(hipMalloc((void**)&c->d_global, sizeof(pcl_diagnostics)));
     PCL_HIP_TRY(hipMemset(c->d_global, 0, sizeof(pcl_diagnostics)));
     return PCL_OK;
@@ -384,24 +389,58 @@ int allreduce_diagnostics(const Span& s)
     return group.end();
 }
 
-// Largest local particle count over all ranks (what every range is padded to in the all-gather).
-// A span that holds every rank (one process driving the whole group) knows it without asking; one
-// process per rank needs an all-reduce and a host synchronisation, per step: a rank cannot know that
-// another rank's count has changed.
-int max_local_count(const Span& s, size_t* out)
+// What the ranks agree on before they step together: the largest local particle count (every range
+// is padded to it in the all-gather) and whether a step carries the pair exchange and the
+// diagnostics all-reduce.  A span that holds every rank (one process driving the whole group) knows
+// all of it without asking.  One process per rank asks once, with one all-reduce (max) and one host
+// synchronisation, and keeps the answer until its own handle's particle set is replaced or its own
+// flags change: ranks make the same calls between the same two steps, so they all ask again at the
+// same step.  Flags found to differ between ranks when they ask come back as an error on every rank
+// instead of a hang on mismatched collectives (a rank that changes its flags alone, without the others
+// reaching a point where they ask, is not caught: the others do not know that there is a question).
+constexpr int kAgreeWords = 5;   // local count, pairs, !pairs, diagnostics, !diagnostics
+
+uint64_t key_epoch(const pcl_compute* h) { return pcl_internal::particles_epoch(h); }
+
+bool agreement_current(const Span& s, bool pairs, bool diag)
 {
+    for (int i = 0; i < s.n; ++i) {
+        const Comm* c = comm_of(s.h[i]);
+        if (!c->agreed || c->agreed_epoch != key_epoch(s.h[i]) || c->agreed_pairs != pairs || c->agreed_diag != diag)
+            return false;
+    }
+    return true;
+}
+
+int agree(const Span& s, bool pairs, bool diag)
+{
+    auto settle = [&](size_t cap) {
+        for (int i = 0; i < s.n; ++i) {
+            Comm* c = comm_of(s.h[i]);
+            c->agreed = true;
+            c->agreed_epoch = key_epoch(s.h[i]);
+            c->agreed_pairs = pairs;
+            c->agreed_diag = diag;
+            c->agreed_cap = cap;
+        }
+    };
     if (s.n == comm_of(s.h[0])->world) {
         size_t most = 0;
         for (int i = 0; i < s.n; ++i) most = std::max(most, pcl_num_particles(s.h[i]));
-        *out = most;
+        settle(most);
         return PCL_OK;
     }
     for (int i = 0; i < s.n; ++i) {
         pcl_compute* h = s.h[i];
         Comm* c = comm_of(h);
+        c->agreed = false;
         if (int rc = pcl_internal::make_current(h)) return rc;
-        *c->h_count = (unsigned long long)pcl_num_particles(h);
-        PCL_HIP_TRY(hipMemcpyAsync(c->d_count, c->h_count, sizeof(unsigned long long), hipMemcpyHostToDevice,
+        c->h_agree[0] = (unsigned long long)pcl_num_particles(h);
+        c->h_agree[1] = pairs ? 1 : 0;
+        c->h_agree[2] = pairs ? 0 : 1;
+        c->h_agree[3] = diag ? 1 : 0;
+        c->h_agree[4] = diag ? 0 : 1;
+        PCL_HIP_TRY(hipMemcpyAsync(c->d_agree, c->h_agree, kAgreeWords * sizeof(unsigned long long), hipMemcpyHostToDevice,
                                    pcl_internal::stream_of(h)));
     }
     {
@@ -411,7 +450,8 @@ int max_local_count(const Span& s, size_t* out)
             pcl_compute* h = s.h[i];
             Comm* c = comm_of(h);
             if (int rc = pcl_internal::make_current(h)) return rc;
-            PCL_NCCL_TRY(g_rccl.AllReduce(c->d_count, c->d_count, 1, ncclUint64, ncclMax, c->comm, pcl_internal::stream_of(h)));
+            PCL_NCCL_TRY(g_rccl.AllReduce(c->d_agree, c->d_agree, kAgreeWords, ncclUint64, ncclMax, c->comm,
+                                          pcl_internal::stream_of(h)));
         }
         if (int rc = group.end()) return rc;
     }
@@ -419,11 +459,16 @@ int max_local_count(const Span& s, size_t* out)
         pcl_compute* h = s.h[i];
         Comm* c = comm_of(h);
         if (int rc = pcl_internal::make_current(h)) return rc;
-        PCL_HIP_TRY(hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+        PCL_HIP_TRY(hipMemcpyAsync(c->h_agree, c->d_agree, kAgreeWords * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                                    pcl_internal::stream_of(h)));
         PCL_HIP_TRY(hipStreamSynchronize(pcl_internal::stream_of(h)));
     }
-    *out = (size_t)*comm_of(s.h[0])->h_count;
+    const unsigned long long* a = comm_of(s.h[0])->h_agree;
+    if (a[1] && a[2])
+        return fail(PCL_ERR_INVALID, "the ranks hold different parameters: the pair term is active on some and inert on others");
+    if (a[3] && a[4])
+        return fail(PCL_ERR_INVALID, "step diagnostics are enabled on some ranks and not on others");
+    settle((size_t)a[0]);
     return PCL_OK;
 }
 
@@ -434,14 +479,19 @@ int step(const Span& s)
 {
     if (int rc = check_span(s)) return rc;
     const bool pairs = pcl_internal::pair_term_active(s.h[0]);
-    for (int i = 1; i < s.n; ++i)
+    const bool diag = pcl_internal::step_diagnostics_enabled(s.h[0]);
+    for (int i = 1; i < s.n; ++i) {
         PCL_REQUIRE(pcl_internal::pair_term_active(s.h[i]) == pairs, "the handles of a group hold different parameters");
+        PCL_REQUIRE(pcl_internal::step_diagnostics_enabled(s.h[i]) == diag,
+                    "step diagnostics are enabled on some handles of a group and not on others");
+    }
+    if (!agreement_current(s, pairs, diag))
+        if (int rc = agree(s, pairs, diag)) return rc;
     if (!pairs) {
         for (int i = 0; i < s.n; ++i)
             if (int rc = pcl_step(s.h[i])) return rc;
     } else {
-        size_t cap = 0;
-        if (int rc = max_local_count(s, &cap)) return rc;
+        const size_t cap = comm_of(s.h[0])->agreed_cap;
         if (cap == 0) {
             for (int i = 0; i < s.n; ++i)
                 if (int rc = pcl_step(s.h[i])) return rc;
@@ -479,7 +529,7 @@ int step(const Span& s)
                 if (int rc = pcl_step_pairs_gathered(s.h[i], comm_of(s.h[i])->d_pair_recv, cap * world)) return rc;
         }
     }
-    if (pcl_internal::step_diagnostics_enabled(s.h[0])) return allreduce_diagnostics(s);
+    if (diag) return allreduce_diagnostics(s);
     return PCL_OK;
 }
 

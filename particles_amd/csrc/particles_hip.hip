@@ -118,6 +118,7 @@ struct pcl_compute {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 
     size_t n = 0;
+    uint64_t particles_epoch = 0;      // counts the calls that replaced the particle set
     size_t capacity = 0;
     char* slab = nullptr;              // one allocation holding every particle array
     float* state[2][6] = {{nullptr}};
@@ -552,6 +553,24 @@ int granted_blocks_per_cu(const void* kernel, int device, int block, size_t lds_
     return PCL_OK;
 }
 
+// Which tiles the blocks of the plain streaming step take (StreamArgs::xcd_chunk; 0: block b takes tile b).
+// Blocks are dealt round-robin over the 8 XCDs, so in tile order every XCD's L2 fetches every field tile that
+// has particles.  That is noise while a field tile holds many blocks' worth of particles, and a second stream
+// when it holds few: 7 redundant fetches of 12 bytes per cell against 49 bytes per particle.  Dealing runs of 128
+// tiles so that each XCD takes 16 consecutive ones removes the redundancy, but costs the streams themselves
+// something at large sets (2^28 particles, 1024^2 field: 2.35-2.39 against 2.20 ms, for any run length from 2
+// up) and gains nothing at small ones (up to 2 * 10^7 particles: within 1 %), so it is used in the window where
+// it was measured to pay: 3 * 2^23 .. 2^26 particles with at most 40 of them per field cell (2^25 particles:
+// 1024^2 field 0.284 against 0.301 ms, 2048^2 field 0.305 against 0.359 ms; 2^26 on 2048^2: 0.588 against
+// 0.622 ms).  Tuning bit 0x100 forces it on, 0x400 off.
+uint32_t xcd_chunk_of(const pcl_compute* h, size_t tiles)
+{
+    if (tiles < 256 || (h->variant & 0x400u)) return 0u;
+    if (h->variant & 0x100u) return 16u;
+    const bool window = h->n >= ((size_t)3 << 23) && h->n <= ((size_t)1 << 26);
+    return (window && h->sorted && h->n <= 40 * h->n_cells) ? 16u : 0u;
+}
+
 // Plain streaming step (field through the caches, no histogram) in blocks of BLOCK threads,
 // one tile of 4 * BLOCK particles per block, at most `cap` blocks per CU (0: whatever fits).
 // A cap that the runtime does not grant exactly (fewer blocks: registers or wave slots bind first;
@@ -565,9 +584,14 @@ int launch_plain_shaped(pcl_compute* h, const pcl::StreamArgs& a, const pcl::Ste
     const size_t groups = h->n / 4;
     const size_t tiles = std::max<size_t>(1, (groups + BLOCK - 1) / BLOCK);
     PCL_REQUIRE(tiles <= 0x7FFFFFFFu, "too many particles for one launch");
-    if (DIAG)
-        if (int rc = reserve_partials(h, (uint32_t)tiles)) return rc;
     pcl::StreamArgs args = a;
+    size_t blocks = tiles;
+    if (const uint32_t k = xcd_chunk_of(h, tiles)) {
+        args.xcd_chunk = k;
+        blocks = (tiles + 8 * k - 1) / (8 * k) * (8 * k);
+    }
+    if (DIAG)
+        if (int rc = reserve_partials(h, (uint32_t)blocks)) return rc;
     args.partials = h->d_partials;
     const void* kernel = reinterpret_cast<const void*>(pcl::step_stream_kernel<DIAG, NT, false, false, BLOCK>);
     size_t pad = occupancy_pad(cap, 0);
@@ -587,10 +611,10 @@ int launch_plain_shaped(pcl_compute* h, const pcl::StreamArgs& a, const pcl::Ste
         }
         pad = 0;
     }
-    hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, false, false, BLOCK>), dim3((uint32_t)tiles), dim3(BLOCK),
+    hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, false, false, BLOCK>), dim3((uint32_t)blocks), dim3(BLOCK),
                        pad, h->stream, args, U, T);
     PCL_HIP_TRY(hipGetLastError());
-    grid = (uint32_t)tiles;   // what the fold of the partials has to cover
+    grid = (uint32_t)blocks;   // what the fold of the partials has to cover
     return PCL_OK;
 }
 
@@ -1135,6 +1159,7 @@ int do_step_impl(pcl_compute* h, int* kind)
             if (int rc = current_field3(h, &packed)) return rc;
             a.field3 = packed;
             a.field_flag = h->d_field_flag;
+            a.xcd_chunk = 0u;
             a.runs = (count && !h->runs_pending) ? h->d_runs : nullptr;
             const bool lds = use_lds_field(h);
             a.lds_cells = lds ? (uint32_t)h->n_cells : 0u;
@@ -1431,6 +1456,7 @@ void* field_of(pcl_compute* h)
 size_t cells_of(const pcl_compute* h) { return h->n_cells; }
 bool pair_term_active(const pcl_compute* h) { return !pair_term_inert(h->params); }
 bool step_diagnostics_enabled(const pcl_compute* h) { return h->step_diag; }
+uint64_t particles_epoch(const pcl_compute* h) { return h->particles_epoch; }
 void set_comm(pcl_compute* h, void* comm, void (*release)(void*)) { h->comm = comm; h->comm_release = release; }
 void* comm_of(const pcl_compute* h) { return h->comm; }
 
@@ -1590,6 +1616,7 @@ int pcl_upload_particles(pcl_compute* h, const pcl_particle* particles, size_t n
     h->slot_of_valid = false;
     h->hist_valid = false;
     h->n = n;
+    ++h->particles_epoch;
     h->diag_current = false;
     if (n == 0) return PCL_OK;
 
@@ -1632,6 +1659,7 @@ int pcl_upload_particles_soa(pcl_compute* h, size_t n, const float* x, const flo
     h->slot_of_valid = false;
     h->hist_valid = false;
     h->n = n;
+    ++h->particles_epoch;
     h->diag_current = false;
     if (n == 0) return PCL_OK;
     for (int a = 0; a < 6; ++a)
@@ -1650,6 +1678,7 @@ int pcl_generate_particles(pcl_compute* h, size_t n, uint64_t seed, uint64_t fir
     h->hist_valid = false;
     if (int rc = reserve_particles(h, n)) return rc;
     h->n = n;
+    ++h->particles_epoch;
     h->diag_current = false;
     if (n == 0) return PCL_OK;
     hipLaunchKernelGGL(pcl::generate_kernel, dim3(linear_grid(h, n)), dim3(pcl::kBlockThreads), 0, h->stream,

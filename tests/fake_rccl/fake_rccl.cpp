@@ -310,9 +310,15 @@ ncclResult_t ncclBroadcast(const void* send, void* recv, size_t count, ncclDataT
     return submit(comm, Op{kBroadcast, send, recv, count, type, ncclSum, root, stream});
 }
 
+// For tests that count what a sequence of library calls puts on the fabric: all-reduce calls this
+// process has made so far, by element type (index = ncclDataType_t, up to 15).
+static unsigned long long g_allreduce_calls[16];
+unsigned long long fake_rccl_allreduce_calls(int type) { return type >= 0 && type < 16 ? g_allreduce_calls[type] : 0; }
+
 ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataType_t type, ncclRedOp_t op, ncclComm_t comm,
                            hipStream_t stream)
 {
+    if ((int)type >= 0 && (int)type < 16) ++g_allreduce_calls[(int)type];
     return submit(comm, Op{kAllReduce, send, recv, count, type, op, 0, stream});
 }
 

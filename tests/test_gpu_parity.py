@@ -113,6 +113,57 @@ def test_automatic_launch_shape_of_large_sets_is_bit_exact(oracle):
             assert_particles_bit_equal(c.read_particles(first, 3000), want, f"slice at {first}")
 
 
+@pytest.mark.parametrize("n,diag,block_bits", [(600003, False, 0x13000000), (1100001, True, 0x03000000),
+                                               (262144 + 5, False, 0x13000000), (2 ** 21 + 2049, False, 0x22000000)])
+def test_plain_step_with_tiles_dealt_per_xcd_is_bit_exact(oracle, n, diag, block_bits):
+    """Tuning bit 0x100: the blocks of the plain step take the tiles in another order (runs of 128
+    tiles, each XCD 16 consecutive ones; the grid is rounded up to a multiple of 128 blocks and
+    the surplus blocks own no tile).  Ragged counts whose last run is partly empty, with and without
+    fused diagnostics (one partial per BLOCK, the empty ones included): bit-equal to the oracle."""
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = (64, 32, 2)
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    g = scene_swirl_field(64, 32, 2, 10.0, seed=17)
+    p = oracle.synth_particles(n, seed=5 + n, pos_extent=20.0, vel_extent=10.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        c.set_tuning(0, 0x100 | block_bits)
+        c.enable_step_diagnostics(diag)
+        for _ in range(3):
+            c.compute()
+        want = oracle.run(sp, p, g, 3, mode=oracle.MODE_SKIP_INERT)
+        assert_particles_bit_equal(c.read_particles(), want, f"n={n}")
+        if diag:
+            d = c.diagnostics()
+            dw = oracle.diagnostics(sp, want)
+            assert d["count"] == dw["count"] == n
+            assert abs(d["kinetic_energy"] - dw["kinetic_energy"]) <= 1e-12 * dw["kinetic_energy"]
+            assert np.array_equal(d["pos_max"], dw["pos_max"]) and np.array_equal(d["pos_min"], dw["pos_min"])
+
+
+def test_automatic_xcd_dealing_in_its_window_is_bit_exact(oracle):
+    """2^25 + 1027 particles in tile order on a 1024^2 field (32 per cell): inside the window in which
+    the plain step deals its tiles per XCD by itself; 26 steps = a refresh cycle and two steps of the
+    next, slices against the oracle."""
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = (1024, 1024, 1)
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    g = scene_swirl_field(1024, 1024, 1, 10.0, seed=11)
+    n = (1 << 25) + 1027
+    with pa.Compute.new(pa.empty_particles(0), g) as c:
+        c.update_sim_params(sp)
+        c.generate_particles(n, seed=98, pos_extent=20.0, vel_extent=10.0)
+        for _ in range(26):
+            c.compute()
+        assert c.reorder_count >= 2
+        for first in (0, 16777216 - 500, n - 2000):
+            p = oracle.synth_particles(2000, seed=98, first_global_index=first, pos_extent=20.0, vel_extent=10.0)
+            want = oracle.run(sp, p, g, 26, mode=oracle.MODE_SKIP_INERT)
+            assert_particles_bit_equal(c.read_particles(first, 2000), want, f"slice at {first}")
+
+
 def test_empty_particle_set():
     sp, p, g = default_scene()
     with pa.Compute.new(p[:0], g) as c:
