@@ -327,7 +327,10 @@ impl Compute {
     }
 
     /// `compute()` of this rank's range, with the all-gather of the pair term and the all-reduce of
-    /// the step diagnostics where those are active.
+    /// the step diagnostics where those are active.  All ranks upload new particle sets and change
+    /// these two settings between the same two steps; the first step after such a change (and after
+    /// attaching) agrees on them with one all-reduce that is read back on the host, and fails on every
+    /// rank when the ranks differ.
     pub fn comm_compute(&mut self) {
         check(unsafe { pcl_comm_step(self.handle) });
     }
