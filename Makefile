@@ -19,7 +19,7 @@ FAKE_RCCL := tests/fake_rccl/libfake_rccl.so
 
 all: $(LIB) oracle $(CPPTEST) $(FAKE_RCCL)
 
-# rocPRIM's radix sort in its own object: it compiles slowly and changes rarely
+# the radix sort of the binned pair term's cell order, in its own object
 $(SORT_OBJ): $(SORT_SRC)
 	mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -Wno-unused-parameter -c -o $@ $(SORT_SRC)

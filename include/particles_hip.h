@@ -368,6 +368,12 @@ int pcl_debug_cell_indices(pcl_compute* h, uint32_t* out, size_t first, size_t c
 int pcl_debug_pair_cells(pcl_compute* h, uint32_t* cell_of_particle, uint32_t* bin_end, size_t bin_capacity,
                          uint32_t* cells_per_axis, uint32_t* reach);
 
+/* Test hook: the caller's index of the particle in every memory slot (the identity
+ * until the library has reordered the set: field-tile order of the streaming step,
+ * cell order of the binned pair term).  No counterpart in the reference, which
+ * never reorders (src/compute.wgsl processes particles in buffer order). */
+int pcl_debug_slot_order(pcl_compute* h, uint32_t* caller_index_of_slot, size_t capacity);
+
 /* Run subsequent work of this handle on `hip_stream` (a hipStream_t owned by
  * the caller, e.g. torch's current stream); NULL restores the internal one. */
 int pcl_set_stream(pcl_compute* h, void* hip_stream);

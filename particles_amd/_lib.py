@@ -92,6 +92,7 @@ SIGNATURES = {
     "pcl_diagnostics_device_noalloc": (_i, [_vp, _vp]),
     "pcl_debug_cell_indices": (_i, [_vp, _vp, _sz, _sz]),
     "pcl_debug_pair_cells": (_i, [_vp, _vp, _vp, _sz, C.POINTER(_u32), C.POINTER(_u32)]),
+    "pcl_debug_slot_order": (_i, [_vp, _vp, _sz]),
     "pcl_set_stream": (_i, [_vp, _vp]),
     "pcl_use_null_stream": (_i, [_vp]),
     "pcl_synchronize": (_i, [_vp]),

@@ -318,6 +318,12 @@ class Compute:
                                                   C.byref(per_axis), C.byref(reach)))
         return cells, bin_end[: per_axis.value ** 3], per_axis.value, reach.value
 
+    def debug_slot_order(self):
+        """Caller index of the particle in every memory slot (the identity until the set is reordered)."""
+        out = np.zeros(self.num_particles, dtype=np.uint32)
+        _lib.check(self._lib.pcl_debug_slot_order(self._h, _ptr(out), out.shape[0]))
+        return out
+
     def set_pair_mode(self, mode):
         """0 automatic, 1 all-pairs sweep in index order (bit-exact), 2 cell-binned."""
         _lib.check(self._lib.pcl_set_pair_mode(self._h, int(mode)))

@@ -812,12 +812,13 @@ void reorder_args(const pcl_compute* h, pcl::ReorderArgs* a)
     a->n = h->n;
 }
 
-// Declared in pair_sort.hip (rocPRIM's stable LSD radix sort of (key, value) pairs on bits
-// [0, end_bit) of the key; with temp == nullptr only the temporary storage size is returned).
+// Defined in pair_sort.hip: stable LSD radix sort of (key, value) pairs on bits [0, end_bit) of the
+// key into keys_out / values_out; the input buffers are overwritten; with temp == nullptr only the
+// temporary storage size is returned.
 }  // namespace
 namespace pcl {
-hipError_t radix_sort_pairs_u32(void* temp, size_t* temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
-                                const uint32_t* values_in, uint32_t* values_out, size_t n, unsigned end_bit,
+hipError_t radix_sort_pairs_u32(void* temp, size_t* temp_bytes, uint32_t* keys_in, uint32_t* keys_out,
+                                uint32_t* values_in, uint32_t* values_out, size_t n, unsigned end_bit,
                                 hipStream_t stream);
 }
 namespace {
@@ -2140,6 +2141,22 @@ int pcl_debug_pair_cells(pcl_compute* h, uint32_t* cell_of_particle, uint32_t* b
             PCL_REQUIRE(caller[slot] < h->n, "pcl_debug_pair_cells: the sort returned an index outside the set");
             cell_of_particle[caller[slot]] = key[slot];
         }
+    return PCL_OK;
+}
+
+int pcl_debug_slot_order(pcl_compute* h, uint32_t* caller_index_of_slot, size_t capacity)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_REQUIRE(caller_index_of_slot != nullptr && capacity >= h->n, "pcl_debug_slot_order: the output is too small");
+    PCL_REQUIRE(h->n <= 0xFFFFFFFFull, "pcl_debug_slot_order: more than 2^32 particles");
+    if (h->n == 0) return PCL_OK;
+    if (h->sorted) {
+        PCL_HIP_TRY(hipMemcpyAsync(caller_index_of_slot, h->orig[h->orig_cur], h->n * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                   h->stream));
+        return sync_stream(h);
+    }
+    if (int rc = sync_stream(h)) return rc;
+    for (size_t i = 0; i < h->n; ++i) caller_index_of_slot[i] = (uint32_t)i;   // still in caller order
     return PCL_OK;
 }
 

@@ -593,8 +593,32 @@ def test_binned_pair_cells_match_the_oracle_bit_for_bit(oracle, n, cutoff, exten
         bad = np.nonzero(cells != want)[0]
         assert bad.size == 0, f"{bad.size} cell keys differ; first {bad[0]}: got {cells[bad[0]]} want {want[bad[0]]} at {p['pos'][bad[0]]}"
         assert np.array_equal(bin_end, np.cumsum(np.bincount(want, minlength=per_axis ** 3)).astype(np.uint32))
+        # the order itself: sorted by cell, inside a cell by ascending caller index (what a stable sort of
+        # (cell, caller index) pairs leaves; the pair sums run in this order)
+        assert np.array_equal(c.debug_slot_order(), np.argsort(want, kind="stable").astype(np.uint32))
         # the sort left the particles in cell order; reads still return caller order
         assert_particles_bit_equal(c.read_particles(), _with_w1(p), "after the cell sort")
+
+
+@pytest.mark.parametrize("n,per_axis_cutoff", [(1, 1.0), (2047, 1.0), (2048, 1.0), (2049, 0.4), (300001, 0.32), (2 ** 21 + 77, 0.32)])
+def test_cell_sort_is_the_stable_sort_by_cell(oracle, n, per_axis_cutoff):
+    """The library's own radix sort (pair_sort.hip) on sizes around its chunk of 2048 elements and
+    over many blocks, with 64 cells per axis (18-bit keys: three passes) and with few cells (one pass):
+    slot order == numpy's stable argsort of the oracle's cell keys."""
+    sp = pair_params(0.0)
+    sp.cut_off_distance = per_axis_cutoff
+    g = sp.new_force_grid_centered().get_force_vectors()
+    p = oracle.synth_particles(n, seed=n + 11, pos_extent=24.0, vel_extent=1.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        assert np.array_equal(c.debug_slot_order(), np.arange(n, dtype=np.uint32))
+        cells, bin_end, per_axis, reach = c.debug_pair_cells()
+        want_axis, want_reach, inv_cell = oracle.pair_cell_map(sp, True, 64 if n >= 2 ** 18 else 20)
+        assert (per_axis, reach) == (want_axis, want_reach)
+        want = oracle.pair_cell_keys(sp, p, per_axis, inv_cell)
+        assert np.array_equal(cells, want)
+        assert np.array_equal(c.debug_slot_order(), np.argsort(want, kind="stable").astype(np.uint32))
+        assert np.array_equal(bin_end, np.cumsum(np.bincount(want, minlength=per_axis ** 3)).astype(np.uint32))
 
 
 def _with_w1(p):
