@@ -318,6 +318,13 @@ class Compute:
                                                   C.byref(per_axis), C.byref(reach)))
         return cells, bin_end[: per_axis.value ** 3], per_axis.value, reach.value
 
+    def debug_state_checksum(self):
+        """(sum, xor) over all particles of a 64-bit mix of (caller index, state bits, type): independent of
+        the order of the particles in memory (see pcl_debug_state_checksum)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        _lib.check(self._lib.pcl_debug_state_checksum(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def debug_slot_order(self):
         """Caller index of the particle in every memory slot (the identity until the set is reordered)."""
         out = np.zeros(self.num_particles, dtype=np.uint32)

@@ -2144,6 +2144,32 @@ int pcl_debug_pair_cells(pcl_compute* h, uint32_t* cell_of_particle, uint32_t* b
     return PCL_OK;
 }
 
+int pcl_debug_state_checksum(pcl_compute* h, uint64_t* sum, uint64_t* xor_of_all)
+{
+    if (int rc = bind(h)) return rc;
+    PCL_REQUIRE(sum != nullptr && xor_of_all != nullptr, "pcl_debug_state_checksum: null output");
+    *sum = *xor_of_all = 0;
+    if (h->n == 0) return sync_stream(h);
+    unsigned long long* d = nullptr;
+    PCL_HIP_TRY(hipMalloc((void**)&d, 2 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, 2 * sizeof(unsigned long long), h->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pcl::state_checksum_kernel, dim3(linear_grid(h, h->n)), dim3(pcl::kBlockThreads), 0, h->stream,
+                           soa_of(h, h->cur), (const uint8_t*)cur_ty(h),
+                           h->sorted ? (const uint32_t*)h->orig[h->orig_cur] : (const uint32_t*)nullptr,
+                           (unsigned long long)h->n, d);
+        e = hipGetLastError();
+    }
+    unsigned long long host[2] = {0ull, 0ull};
+    if (e == hipSuccess) e = hipMemcpyAsync(host, d, sizeof host, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(PCL_ERR_HIP, std::string("pcl_debug_state_checksum: ") + hipGetErrorString(e));
+    *sum = host[0];
+    *xor_of_all = host[1];
+    return sync_stream(h);
+}
+
 int pcl_debug_slot_order(pcl_compute* h, uint32_t* caller_index_of_slot, size_t capacity)
 {
     if (int rc = bind(h)) return rc;

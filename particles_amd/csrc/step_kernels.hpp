@@ -1226,6 +1226,44 @@ __global__ __launch_bounds__(kBlockThreads) void cell_index_kernel(
     }
 }
 
+// Order-independent checksum of the whole state: every particle contributes a 64-bit mix of its
+// caller index, its six state words and its type; the contributions are summed (mod 2^64) and
+// xor-ed, both of which do not care in which order, or by whom, they are combined.  Two states give
+// the same pair iff (up to collisions of the mix) every caller index holds the same bits.
+// orig: caller index of every slot, or null while the slots are in caller order.
+__device__ __forceinline__ unsigned long long checksum_mix(unsigned long long h, uint32_t w)
+{
+    h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+    return h ^ (h >> 32);
+}
+
+__global__ __launch_bounds__(kBlockThreads) void state_checksum_kernel(
+    StateSoA s, const uint8_t* __restrict__ ty, const uint32_t* __restrict__ orig, unsigned long long n,
+    unsigned long long* __restrict__ out /* sum, xor */)
+{
+    __shared__ unsigned long long block_sum, block_xor;
+    if (threadIdx.x == 0) { block_sum = 0ull; block_xor = 0ull; }
+    __syncthreads();
+    unsigned long long sum = 0ull, x = 0ull;
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x; i < n; i += stride) {
+        const unsigned long long caller = orig ? orig[i] : i;
+        unsigned long long h = (caller + 1ull) * 0x9E3779B97F4A7C15ull;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) h = checksum_mix(h, __float_as_uint(s.a[c][i]));
+        h = checksum_mix(h, ty[i]);
+        sum += h;
+        x ^= h;
+    }
+    atomicAdd(&block_sum, sum);
+    atomicXor(&block_xor, x);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&out[0], block_sum);
+        atomicXor(&out[1], block_xor);
+    }
+}
+
 // Whether a field cell lies inside the window of the packed path: every component zero or
 // within [2^-60, 2^60] in magnitude (NaN and infinities are outside).
 __device__ __forceinline__ bool cell_in_window(float x, float y, float z)

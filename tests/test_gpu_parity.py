@@ -391,6 +391,83 @@ def test_full_size_slices_match_oracle(oracle, log2n):
         assert c.diagnostics()["count"] == n
 
 
+def _state_checksum(p):
+    """numpy twin of pcl_debug_state_checksum over records in caller order."""
+    M = np.uint64(0xFF51AFD7ED558CCD)
+    with np.errstate(over="ignore"):
+        h = (np.arange(p.shape[0], dtype=np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        words = [p["pos"][:, k].view(np.uint32) for k in range(3)] + [p["vel"][:, k].view(np.uint32) for k in range(3)] + [p["ty"]]
+        for w in words:
+            h = (h ^ w.astype(np.uint64)) * M
+            h = h ^ (h >> np.uint64(32))
+        return int(h.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(h))
+
+
+@pytest.mark.parametrize("n", [1, 1000, 300007])
+def test_state_checksum_matches_its_numpy_twin_in_any_memory_order(oracle, n):
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = (64, 64, 1)
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    g = scene_swirl_field(64, 64, 1, 10.0, seed=3)
+    p = oracle.synth_particles(n, seed=n, pos_extent=20.0, vel_extent=10.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        q = p.copy(); q["pos"][:, 3] = 1.0; q["vel"][:, 3] = 1.0
+        assert c.debug_state_checksum() == _state_checksum(q)
+        c.set_reorder_interval(2)
+        for _ in range(5):
+            c.compute()
+        if n >= 4096:
+            assert c.reorder_count >= 2 and not np.array_equal(c.debug_slot_order(), np.arange(n, dtype=np.uint32))
+        got = c.read_particles()
+        assert c.debug_state_checksum() == _state_checksum(got)
+        # one bit of one particle changes both words
+        got["vel"][n // 2, 1] = np.nextafter(got["vel"][n // 2, 1], np.float32(np.inf))
+        a, b = _state_checksum(got)
+        assert a != c.debug_state_checksum()[0] and b != c.debug_state_checksum()[1]
+
+
+@pytest.mark.parametrize("log2n", [28, 30])
+def test_every_particle_of_a_full_size_run_agrees_between_independent_kernel_paths(oracle, log2n):
+    """BASELINE's full sizes, EVERY particle: the headline workload (2^28 particles, 1024^2 field) and 2^30
+    particles stepped (a) as shipped (packed arithmetic, tile order refreshed by the counting and scatter
+    steps, per-XCD launch shape), (b) on the scalar path with full divisions, the particles never moved
+    from caller order, (c) through pcl_step_n's fused launches.  The three states must agree in an
+    order-independent checksum over all particles (caller index, six state words, type); slices of (a)
+    are held to the oracle in test_full_size_slices_match_oracle, and the checksum itself to its numpy twin."""
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = (1024, 1024, 1)
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    g = scene_swirl_field(1024, 1024, 1, 10.0, seed=5)
+    n = 1 << log2n
+    steps = 52 if log2n == 28 else 27
+    sums = {}
+    for name, variant, interval in (("shipped", 0, -1), ("scalar, caller order", 0x4, 0), ("fused", 0, -1)):
+        with pa.Compute.new(pa.empty_particles(0), g) as c:
+            c.update_sim_params(sp)
+            c.set_tuning(0, variant)
+            c.set_reorder_interval(interval)
+            c.generate_particles(n, seed=2025, pos_extent=20.0, vel_extent=10.0)
+            if name == "fused":
+                c.step_n(steps)
+            else:
+                for _ in range(steps):
+                    c.compute()
+            if interval == 0:
+                assert c.reorder_count == 0
+            else:
+                assert c.reorder_count >= 3
+            sums[name] = c.debug_state_checksum()
+            if name == "shipped":     # anchor: one slice against the oracle
+                first = n // 3
+                p = oracle.synth_particles(1000, seed=2025, first_global_index=first, pos_extent=20.0, vel_extent=10.0)
+                want = oracle.run(sp, p, g, steps, mode=oracle.MODE_SKIP_INERT)
+                assert_particles_bit_equal(c.read_particles(first, 1000), want, f"2^{log2n} slice at {first}")
+    assert sums["shipped"] == sums["scalar, caller order"] == sums["fused"], sums
+
+
 def test_config4_share_with_diagnostics_every_step_through_the_library_communicator(oracle):
     """One GPU's share of BASELINE configuration 4 (2^30 particles over 8 GPUs = 2^27 each, 1024^2 field,
     diagnostics all-reduced every step), stepped through pcl_comm_step on a one-rank RCCL communicator
