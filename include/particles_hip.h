@@ -376,13 +376,16 @@ int pcl_debug_slot_order(pcl_compute* h, uint32_t* caller_index_of_slot, size_t 
 
 /* Test hook: a checksum of the whole current state that does not depend on the
  * order of the particles in memory.  Particle i (caller order) contributes
- *   h = (i + 1) * 0x9E3779B97F4A7C15;  for w in (x, y, z, vx, vy, vz bits, type):
+ *   h = (first_global_index + i + 1) * 0x9E3779B97F4A7C15;  for w in (x, y, z, vx, vy, vz bits, type):
  *   h = (h ^ w) * 0xFF51AFD7ED558CCD; h ^= h >> 32          (all mod 2^64)
  * and *sum / *xor_of_all receive the sum and the xor of the contributions: two
  * handles agree on both iff, up to collisions, every particle has the same bits
  * in both.  For comparing states too large to read back (a whole 2^28-particle
- * run on two different kernel paths).  No counterpart in the reference. */
-int pcl_debug_state_checksum(pcl_compute* h, uint64_t* sum, uint64_t* xor_of_all);
+ * run on two different kernel paths); with first_global_index = the first index
+ * of a handle's range, the sums of the ranges add up (mod 2^64) and their xors
+ * xor to the words of one handle holding the whole set.  No counterpart in the
+ * reference. */
+int pcl_debug_state_checksum(pcl_compute* h, uint64_t first_global_index, uint64_t* sum, uint64_t* xor_of_all);
 
 /* Run subsequent work of this handle on `hip_stream` (a hipStream_t owned by
  * the caller, e.g. torch's current stream); NULL restores the internal one. */

@@ -318,11 +318,12 @@ class Compute:
                                                   C.byref(per_axis), C.byref(reach)))
         return cells, bin_end[: per_axis.value ** 3], per_axis.value, reach.value
 
-    def debug_state_checksum(self):
-        """(sum, xor) over all particles of a 64-bit mix of (caller index, state bits, type): independent of
-        the order of the particles in memory (see pcl_debug_state_checksum)."""
+    def debug_state_checksum(self, first_global_index=0):
+        """(sum, xor) over all particles of a 64-bit mix of (global index, state bits, type): independent of
+        the order of the particles in memory; the words of index ranges combine (sum mod 2^64, xor) to
+        those of the whole set (see pcl_debug_state_checksum)."""
         a, b = C.c_uint64(), C.c_uint64()
-        _lib.check(self._lib.pcl_debug_state_checksum(self._h, C.byref(a), C.byref(b)))
+        _lib.check(self._lib.pcl_debug_state_checksum(self._h, int(first_global_index), C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
     def debug_slot_order(self):

@@ -2144,7 +2144,7 @@ int pcl_debug_pair_cells(pcl_compute* h, uint32_t* cell_of_particle, uint32_t* b
     return PCL_OK;
 }
 
-int pcl_debug_state_checksum(pcl_compute* h, uint64_t* sum, uint64_t* xor_of_all)
+int pcl_debug_state_checksum(pcl_compute* h, uint64_t first_global_index, uint64_t* sum, uint64_t* xor_of_all)
 {
     if (int rc = bind(h)) return rc;
     PCL_REQUIRE(sum != nullptr && xor_of_all != nullptr, "pcl_debug_state_checksum: null output");
@@ -2157,7 +2157,7 @@ int pcl_debug_state_checksum(pcl_compute* h, uint64_t* sum, uint64_t* xor_of_all
         hipLaunchKernelGGL(pcl::state_checksum_kernel, dim3(linear_grid(h, h->n)), dim3(pcl::kBlockThreads), 0, h->stream,
                            soa_of(h, h->cur), (const uint8_t*)cur_ty(h),
                            h->sorted ? (const uint32_t*)h->orig[h->orig_cur] : (const uint32_t*)nullptr,
-                           (unsigned long long)h->n, d);
+                           (unsigned long long)h->n, (unsigned long long)first_global_index, d);
         e = hipGetLastError();
     }
     unsigned long long host[2] = {0ull, 0ull};

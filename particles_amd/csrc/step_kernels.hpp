@@ -1239,7 +1239,7 @@ __device__ __forceinline__ unsigned long long checksum_mix(unsigned long long h,
 
 __global__ __launch_bounds__(kBlockThreads) void state_checksum_kernel(
     StateSoA s, const uint8_t* __restrict__ ty, const uint32_t* __restrict__ orig, unsigned long long n,
-    unsigned long long* __restrict__ out /* sum, xor */)
+    unsigned long long first_index, unsigned long long* __restrict__ out /* sum, xor */)
 {
     __shared__ unsigned long long block_sum, block_xor;
     if (threadIdx.x == 0) { block_sum = 0ull; block_xor = 0ull; }
@@ -1248,7 +1248,7 @@ __global__ __launch_bounds__(kBlockThreads) void state_checksum_kernel(
     const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
     for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x; i < n; i += stride) {
         const unsigned long long caller = orig ? orig[i] : i;
-        unsigned long long h = (caller + 1ull) * 0x9E3779B97F4A7C15ull;
+        unsigned long long h = (first_index + caller + 1ull) * 0x9E3779B97F4A7C15ull;
 #pragma unroll
         for (int c = 0; c < 6; ++c) h = checksum_mix(h, __float_as_uint(s.a[c][i]));
         h = checksum_mix(h, ty[i]);

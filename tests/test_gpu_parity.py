@@ -468,6 +468,40 @@ def test_every_particle_of_a_full_size_run_agrees_between_independent_kernel_pat
     assert sums["shipped"] == sums["scalar, caller order"] == sums["fused"], sums
 
 
+@pytest.mark.parametrize("shards", [2, 8])
+def test_index_range_shards_of_the_headline_workload_add_up_to_the_unsharded_run(oracle, shards):
+    """BASELINE configuration 3 under strong scaling, every particle: 2^28 particles on the 1024^2 field split
+    by index range into 2 and 8 handles (2^27 and 2^25 particles each: the shares of 2 and 8 GPUs; the latter
+    inside the window where the plain step deals its tiles per XCD), each generating and stepping its own range
+    for 52 steps with everything automatic, exactly as a rank does.  With the pair term inert no rank needs
+    another, so the handles run one after the other on this GPU.  The ranges' checksums (each with its first
+    global index) must combine -- sums mod 2^64, xors -- to the words of ONE handle holding all 2^28."""
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = (1024, 1024, 1)
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    g = scene_swirl_field(1024, 1024, 1, 10.0, seed=5)
+    n, steps = 1 << 28, 52
+
+    def run(first, count):
+        with pa.Compute.new(pa.empty_particles(0), g) as c:
+            c.update_sim_params(sp)
+            c.generate_particles(count, seed=2025, first_global_index=first, pos_extent=20.0, vel_extent=10.0)
+            for _ in range(steps):
+                c.compute()
+            assert c.reorder_count >= 4
+            return c.debug_state_checksum(first)
+
+    whole = run(0, n)
+    total, xored = 0, 0
+    for rank in range(shards):
+        first, last = pa.shard_range(n, rank, shards)
+        a, b = run(first, last - first)
+        total = (total + a) % (1 << 64)
+        xored ^= b
+    assert (total, xored) == whole
+
+
 def test_config4_share_with_diagnostics_every_step_through_the_library_communicator(oracle):
     """One GPU's share of BASELINE configuration 4 (2^30 particles over 8 GPUs = 2^27 each, 1024^2 field,
     diagnostics all-reduced every step), stepped through pcl_comm_step on a one-rank RCCL communicator
