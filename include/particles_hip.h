@@ -166,8 +166,11 @@ int pcl_patch_force_grid_device(pcl_compute* h, size_t first_cell,
 /* Brush edit of a list of cells: field[cell_indices[i]] = cells[i].  Replaces
  * the write loop of Cursor::mouse_moved, src/cursor.rs:84-101 (grid.grid[ix]
  * for ix in modify_vector_indices) followed by the whole-field re-upload of
- * src/main.rs:371-380.  The _device form takes both lists from device memory
- * (u32 indices; out-of-range indices are skipped) and is ordered on the stream. */
+ * src/main.rs:371-380.  An index listed more than once ends up holding its LAST
+ * cell, as after the reference's sequential loop.  The _device form takes both
+ * lists from device memory (u32 indices; out-of-range indices are skipped) and
+ * is ordered on the stream; there an index listed more than once ends up with
+ * one of its cells, which one is not defined. */
 int pcl_patch_force_grid_indexed(pcl_compute* h, const uint32_t* cell_indices,
                                  const float (*cells)[4], size_t count);
 int pcl_patch_force_grid_indexed_device(pcl_compute* h, const void* dev_cell_indices,

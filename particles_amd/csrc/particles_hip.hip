@@ -25,6 +25,7 @@
 #include <new>
 #include <string>
 #include <utility>
+#include <unordered_set>
 #include <vector>
 
 static_assert(sizeof(pcl_particle) == 48, "Particle is 48 bytes (src/main.rs:76-83)");
@@ -1440,6 +1441,23 @@ int brush_mouse_moved(pcl_compute* h, const pcl_brush_input* host_in, const void
     return PCL_OK;
 }
 
+// The listed cells into the 16-byte field, then (a second launch: the first must have finished) the
+// packed copy of those cells from the field as it ended up.
+hipError_t launch_indexed_patch(pcl_compute* h, const uint32_t* d_index, const pcl::f32x4* d_cells, size_t count)
+{
+    hipLaunchKernelGGL(pcl::patch_field_kernel, dim3(linear_grid(h, count)), dim3(pcl::kBlockThreads), 0, h->stream,
+                       h->field, live_field_flag(h), (unsigned long long)h->n_cells, d_index, d_cells,
+                       (unsigned long long)count);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    if (float* packed = live_field3(h)) {
+        hipLaunchKernelGGL(pcl::repack_cells_kernel, dim3(linear_grid(h, count)), dim3(pcl::kBlockThreads), 0, h->stream,
+                           (const pcl::f32x4*)h->field, packed, (unsigned long long)h->n_cells, d_index,
+                           (unsigned long long)count);
+        return hipGetLastError();
+    }
+    return hipSuccess;
+}
+
 }  // namespace
 
 namespace pcl_internal {
@@ -1736,18 +1754,38 @@ int pcl_patch_force_grid_indexed(pcl_compute* h, const uint32_t* cell_indices, c
         if (cell_indices[i] >= h->n_cells)
             return fail(PCL_ERR_OUT_OF_RANGE, "pcl_patch_force_grid_indexed: cell index " +
                                                   std::to_string(cell_indices[i]) + " is outside the field");
+    // The reference's loop writes the listed cells one after the other, so of several occurrences of an
+    // index the last one stays: keep only that one (the kernel's order of writes is not defined).
+    std::vector<uint32_t> keep_index;
+    std::vector<float> keep_cells;
+    {
+        std::unordered_set<uint32_t> seen;
+        seen.reserve(count * 2);
+        bool duplicates = false;
+        for (size_t i = 0; i < count && !duplicates; ++i) duplicates = !seen.insert(cell_indices[i]).second;
+        if (duplicates) {
+            seen.clear();
+            std::vector<size_t> last;   // positions that survive, descending
+            for (size_t i = count; i-- > 0;)
+                if (seen.insert(cell_indices[i]).second) last.push_back(i);
+            keep_index.reserve(last.size());
+            keep_cells.reserve(last.size() * 4);
+            for (size_t k = last.size(); k-- > 0;) {
+                keep_index.push_back(cell_indices[last[k]]);
+                keep_cells.insert(keep_cells.end(), cells[last[k]], cells[last[k]] + 4);
+            }
+            cell_indices = keep_index.data();
+            cells = reinterpret_cast<const float (*)[4]>(keep_cells.data());
+            count = keep_index.size();
+        }
+    }
     char* staging = nullptr;
     PCL_HIP_TRY(hipMalloc((void**)&staging, count * (sizeof(pcl::f32x4) + sizeof(uint32_t))));
     pcl::f32x4* d_cells = reinterpret_cast<pcl::f32x4*>(staging);
     uint32_t* d_index = reinterpret_cast<uint32_t*>(staging + count * sizeof(pcl::f32x4));
     hipError_t e = hipMemcpyAsync(d_cells, cells, count * sizeof(pcl::f32x4), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_index, cell_indices, count * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(pcl::patch_field_kernel, dim3(linear_grid(h, count)), dim3(pcl::kBlockThreads), 0, h->stream,
-                           h->field, live_field3(h), live_field_flag(h), (unsigned long long)h->n_cells,
-                           (const uint32_t*)d_index, (const pcl::f32x4*)d_cells, (unsigned long long)count);
-        e = hipGetLastError();
-    }
+    if (e == hipSuccess) e = launch_indexed_patch(h, d_index, d_cells, count);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     (void)hipFree(staging);
     if (e != hipSuccess) return fail(PCL_ERR_HIP, std::string("pcl_patch_force_grid_indexed: ") + hipGetErrorString(e));
@@ -1759,11 +1797,8 @@ int pcl_patch_force_grid_indexed_device(pcl_compute* h, const void* dev_cell_ind
     if (int rc = bind(h)) return rc;
     if (count == 0) return PCL_OK;
     PCL_REQUIRE(dev_cell_indices != nullptr && dev_cells != nullptr, "pcl_patch_force_grid_indexed_device: null argument");
-    hipLaunchKernelGGL(pcl::patch_field_kernel, dim3(linear_grid(h, count)), dim3(pcl::kBlockThreads), 0, h->stream,
-                       h->field, live_field3(h), live_field_flag(h), (unsigned long long)h->n_cells,
-                       reinterpret_cast<const uint32_t*>(dev_cell_indices), reinterpret_cast<const pcl::f32x4*>(dev_cells),
-                       (unsigned long long)count);
-    PCL_HIP_TRY(hipGetLastError());
+    PCL_HIP_TRY(launch_indexed_patch(h, reinterpret_cast<const uint32_t*>(dev_cell_indices),
+                                     reinterpret_cast<const pcl::f32x4*>(dev_cells), count));
     return PCL_OK;
 }
 

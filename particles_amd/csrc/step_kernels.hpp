@@ -1296,10 +1296,14 @@ __global__ __launch_bounds__(kBlockThreads) void prepare_field_kernel(
 
 // field[index[i]] = cells[i]: brush edits rewrite a list of cells
 // (src/cursor.rs:79-103 writes grid.grid[ix] for ix in modify_vector_indices).
-// `field3` (may be null): the packed copy, kept equal.
 // `field_flag` (may be null): see prepare_field_kernel; raised when a patched cell leaves the window.
+// An index that occurs more than once: one of its cells wins, which one is not defined (the host entry
+// point removes all but the last occurrence first, which is what the reference's sequential loop leaves).
+// The packed copy is brought up to date by repack_cells_kernel in a second launch, from the cells as
+// they ended up: written here from cells[i], two occurrences of an index could leave the two copies of
+// the field with different winners.
 __global__ __launch_bounds__(kBlockThreads) void patch_field_kernel(
-    f32x4* __restrict__ field, float* __restrict__ field3, uint32_t* __restrict__ field_flag, unsigned long long n_cells,
+    f32x4* __restrict__ field, uint32_t* __restrict__ field_flag, unsigned long long n_cells,
     const uint32_t* __restrict__ index, const f32x4* __restrict__ cells, unsigned long long count)
 {
     const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
@@ -1309,8 +1313,23 @@ __global__ __launch_bounds__(kBlockThreads) void patch_field_kernel(
         if (c < n_cells) {
             const f32x4 v = cells[i];
             field[c] = v;
-            if (field3) { field3[3ull * c] = v.x; field3[3ull * c + 1] = v.y; field3[3ull * c + 2] = v.z; }
             if (field_flag && !cell_in_window(v.x, v.y, v.z)) atomicOr(field_flag, 1u);
+        }
+    }
+}
+
+// field3[3c .. 3c+2] = field[c].xyz for the listed cells (after patch_field_kernel has finished).
+__global__ __launch_bounds__(kBlockThreads) void repack_cells_kernel(
+    const f32x4* __restrict__ field, float* __restrict__ field3, unsigned long long n_cells,
+    const uint32_t* __restrict__ index, unsigned long long count)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * kBlockThreads;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlockThreads + threadIdx.x;
+         i < count; i += stride) {
+        const uint32_t c = index[i];
+        if (c < n_cells) {
+            const f32x4 v = field[c];
+            field3[3ull * c] = v.x; field3[3ull * c + 1] = v.y; field3[3ull * c + 2] = v.z;
         }
     }
 }

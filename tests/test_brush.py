@@ -102,6 +102,37 @@ def test_brush_patch_reaches_the_device(oracle):
             c.patch_force_grid_indexed([1000], np.ones((1, 4), dtype=F))
 
 
+@pytest.mark.gpu
+def test_indexed_patch_with_repeated_indices_keeps_the_last_occurrence_in_both_field_copies(oracle):
+    """The reference writes the listed cells one after the other (src/cursor.rs:84-101), so of several
+    occurrences of an index the last stays.  The host entry point must give exactly that, in the 16-byte
+    field that reads return AND in the packed copy the streaming kernels fetch from (a step after the
+    patch is held to the oracle stepping on the field a sequential loop leaves)."""
+    sp = pa.SimParams()
+    sp.delta_t = F(1.0 / 60.0)
+    sp.force_grid_dimensions = (64, 64, 4)     # 256 KiB of cells: the packed copy is in use
+    rng = np.random.default_rng(77)
+    g = np.ones((64 * 64 * 4, 4), dtype=F)
+    g[:, :3] = rng.uniform(-2, 2, size=(g.shape[0], 3)).astype(F)
+    p = oracle.synth_particles(20000, seed=78, pos_extent=20.0, vel_extent=4.0)
+    with pa.Compute.new(p, g) as c:
+        c.update_sim_params(sp)
+        c.compute()                             # the packed copy exists from here on
+        cur = oracle.step(sp, p, g)
+        for trial in range(5):
+            count = 5000
+            idx = rng.integers(0, 600, size=count).astype(np.uint32)     # every index about eight times
+            cells = np.ones((count, 4), dtype=F)
+            cells[:, :3] = rng.uniform(-3, 3, size=(count, 3)).astype(F)
+            for i in range(count):                                     # what a sequential loop leaves
+                g[idx[i]] = cells[i]
+            c.patch_force_grid_indexed(idx, cells)
+            assert np.array_equal(c.read_force_grid(), g), f"trial {trial}: the 16-byte field"
+            c.compute()
+            cur = oracle.step(sp, cur, g)
+            assert_particles_bit_equal(c.read_particles(), cur, f"trial {trial}: a step on the packed copy")
+
+
 # ---- the oracle's restatement of the brush, the numpy mirror and the device brush ----
 
 MODES = ("centered", "shift", "rotate")
