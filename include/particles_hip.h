@@ -478,7 +478,8 @@ int pcl_launch_residency(const pcl_compute* h, uint32_t* intended_blocks_per_cu,
  *   0x1      plain instead of non-temporal access to the particle arrays
  *   0x2      never stage the field in LDS
  *   0x8      separate counting pass instead of the counting step
- *   0xF0     log2 of the cells per sort tile (default 8 = 16 x 16 cells)
+ *   0xF0     log2 of the cells per sort tile (automatic: 8 to 10, i.e. 16 x 16 to 32 x 32 cells of a flat field, more the
+ *            fewer particles a cell holds)
  *   0xF000   point of the refresh interval the tile order aims at, in tenths (default 5)
  *   0x10000  cut-off cells of the binned pair term: one-cell reach only
  *   0x20000  cut-off cells: at most 20 per axis

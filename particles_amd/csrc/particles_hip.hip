@@ -700,7 +700,7 @@ uint32_t floor_log2(uint32_t v)
     return l;
 }
 
-// Tiles of at most 256 cells (4 KiB of field), z extent first because z is the
+// Tiles of at most 2^log2_tile_cells cells (256: 4 KiB of field), z extent first because z is the
 // fastest-varying cell coordinate; tiles grow until there are at most
 // kMaxReorderBins of them.
 pcl::TileMap make_tile_map(const pcl_sim_params& p, int interval, uint32_t log2_tile_cells = 8, float aim = 0.5f)
@@ -734,11 +734,26 @@ pcl::TileMap make_tile_map(const pcl_sim_params& p, int interval, uint32_t log2_
     return T;
 }
 
-// log2 of the cells per sort tile (tuning: variant bits 4..7 override the default of 8 = 16x16 cells).
+// log2 of the cells per sort tile (tuning: variant bits 4..7 override it).
+// The sort tile trades the two costs of the order against each other: small tiles keep a block's field cells
+// few, large tiles give the refresh long runs per bin (fewer reservations, fewer partial lines).  Since the
+// particles of a bin are sub-ordered by where they came from (see do_step_impl: the first sort in two passes),
+// a block's cells stay few in larger tiles too, and the plain step hardly notices the tile size (2^28
+// particles on 1024^2 cells: 2.211 ms with 256-cell tiles, 2.213 with 512, 2.22 with 1024, 2.235 with 2048),
+// while the scatter step does (4.28 / 3.97 / 3.83 / 3.65 ms).  The fewer particles a cell holds the shorter
+// the runs and the more a larger tile pays: whole step at 2^28 (256 per cell) +0.4 % with 512 cells, at 2^27
+// +0.7 %, 2^26 +1.3 %, 2^25 +2.2 %, 2^24 (16 per cell) +2.1 % with 1024 cells.  With fused diagnostics (512-thread
+// blocks, whose field footprint is twice as large) one size smaller.  Never fewer than 256 tiles: their
+// cursors are what the blocks' reservations spread over.
 uint32_t tile_log2(const pcl_compute* h)
 {
     const uint32_t v = (h->variant >> 4) & 0xFu;
-    return v ? v : 8u;
+    if (v) return v;
+    const size_t per_cell = h->n / std::max<size_t>(h->n_cells, 1);
+    uint32_t want = per_cell <= 128 ? 10u : 9u;
+    if (h->step_diag) want -= 1u;
+    while (want > 8u && (h->n_cells >> want) < 256u) --want;
+    return want;
 }
 
 // Which point of the refresh interval the order is aimed at, as a fraction of
