@@ -75,7 +75,7 @@ constexpr uint32_t kLdsFieldMaxBytes = 64u * 1024u;  // fields up to this size a
 // 4.7 at 32, 6.2 at 64: a tile's particles spread over more bins).
 constexpr int kAutoReorderInterval = 24;
 constexpr size_t kPairWideMinParticles = size_t(1) << 18;   // below: the sort over many cells costs more than the sweep saves
-constexpr size_t kHistEntries = (size_t)pcl::kMaxReorderBins * pcl::kCursorGroups;   // counters (and cursors) in d_hist
+constexpr size_t kHistEntries = (size_t)pcl::kMaxReorderBins * pcl::kMaxCursorGroups;   // counters (and cursors) in d_hist
 constexpr uint32_t kPairMaxCellsPerAxis = 64;          // cut-off cells per axis (beyond 20: counters in global memory)
 constexpr int kAutoReorderMaxInterval = 96;           // automatic pacing never waits longer than this
 constexpr size_t kAutoReorderMinFieldBytes = 16u * 1024u;        // up to here the vector L1 holds the field well enough
@@ -135,11 +135,12 @@ struct pcl_compute {
     int orig_cur = 0;
     uint32_t* slot_of = nullptr;       // inverse of orig, built on demand
     bool slot_of_valid = false;
-    uint32_t* d_hist = nullptr;        // kMaxReorderBins * kCursorGroups counters, as many cursors, as many range ends
+    uint32_t* d_hist = nullptr;        // kMaxReorderBins * kMaxCursorGroups counters, as many cursors, as many range ends
     size_t reorder_capacity = 0;
     uint64_t steps_since_sort = 0;
     bool hist_valid = false;           // d_hist counts the tile keys of state[cur] (left by a counting step)
     pcl::TileMap hist_tiles;           // the key function that histogram was taken with
+    uint32_t hist_groups = 4;          // and its cursor groups
     uint64_t reorders = 0;
     // sort by cut-off cell for the binned pair term (stable radix sort of (cell, caller index))
     uint32_t* d_cellsort = nullptr;    // key in, key out, index in, index out: 4 x capacity
@@ -734,6 +735,13 @@ pcl::TileMap make_tile_map(const pcl_sim_params& p, int interval, uint32_t log2_
     return T;
 }
 
+// Cursor groups of a refresh (reorder_kernels.hpp: kMaxCursorGroups): 8 above 65536 particles per bin
+// (more than 32 scatter blocks reserving in every bin), 4 below.
+uint32_t cursor_groups(const pcl_compute* h, const pcl::TileMap& T)
+{
+    return h->n / std::max<uint32_t>(T.n_bins, 1u) > 65536u ? pcl::kMaxCursorGroups : 4u;
+}
+
 // log2 of the cells per sort tile (tuning: variant bits 4..7 override it).
 // The sort tile trades the two costs of the order against each other: small tiles keep a block's field cells
 // few, large tiles give the refresh long runs per bin (fewer reservations, fewer partial lines).  Since the
@@ -947,10 +955,11 @@ int do_reorder(pcl_compute* h, float aim)
     if (int rc = reserve_reorder(h)) return rc;
     const pcl::TileMap T = make_tile_map(h->params, effective_reorder_interval(h), tile_log2(h), aim);
     const pcl::StepUniforms U = uniforms_of(h);
-    if (int rc = reorder_count(h, U, T, pcl::kCursorGroups)) return rc;
+    const uint32_t groups = cursor_groups(h, T);
+    if (int rc = reorder_count(h, U, T, groups)) return rc;
     pcl::ReorderArgs a;
     uint32_t grid = 0;
-    if (int rc = reorder_prepare(h, T, pcl::kCursorGroups, &a, &grid)) return rc;
+    if (int rc = reorder_prepare(h, T, groups, &a, &grid)) return rc;
     hipLaunchKernelGGL(pcl::reorder_scatter_kernel, dim3(grid), dim3(pcl::kStreamThreads),
                        pcl::scatter_lds_bytes(T.n_bins), h->stream, a, U, T);
     PCL_HIP_TRY(hipGetLastError());
@@ -1096,6 +1105,7 @@ int do_step_impl(pcl_compute* h, int* kind)
         const bool sort_now = interval > 0 && (!h->sorted || h->steps_since_sort >= (uint64_t)interval);
         // A pending histogram fixes the key function (delta_t, hence the lookahead, may change per frame).
         pcl::TileMap T = (sort_now && h->hist_valid) ? h->hist_tiles : make_tile_map(h->params, interval, tile_log2(h), tile_aim(h));
+        const uint32_t groups = (sort_now && h->hist_valid) ? h->hist_groups : cursor_groups(h, T);
         // tuning bit 0x40000 (tests only): scatter with other keys than the pending histogram counted,
         // which the scatter kernel must detect and report through the error word
         if (sort_now && h->hist_valid && (h->variant & 0x40000u)) T.lookahead += 1.0f;
@@ -1111,9 +1121,9 @@ int do_step_impl(pcl_compute* h, int* kind)
             // Update and scatter into tile order in one pass.
             if (int rc = reserve_reorder(h)) return rc;
             if (!h->hist_valid)
-                if (int rc = reorder_count(h, U, T, pcl::kCursorGroups)) return rc;
+                if (int rc = reorder_count(h, U, T, groups)) return rc;
             pcl::StepScatterArgs sa;
-            if (int rc = reorder_prepare(h, T, pcl::kCursorGroups, &sa.r, &grid)) return rc;
+            if (int rc = reorder_prepare(h, T, groups, &sa.r, &grid)) return rc;
             if (h->step_diag)
                 if (int rc = reserve_partials(h, grid)) return rc;
             sa.field = h->field;
@@ -1144,7 +1154,7 @@ int do_step_impl(pcl_compute* h, int* kind)
                 // One tile per block here too: blocks dispatched together then work on
                 // neighbouring tiles, which is what keeps the field fetches cache-resident
                 // (a persistent grid striding over the array measured 15 % slower).
-                PCL_HIP_TRY(hipMemsetAsync(h->d_hist, 0, (size_t)T.n_bins * pcl::kCursorGroups * sizeof(uint32_t), h->stream));
+                PCL_HIP_TRY(hipMemsetAsync(h->d_hist, 0, (size_t)T.n_bins * groups * sizeof(uint32_t), h->stream));
                 // one tile per block whatever the grid cap says: the counter group is the tile's residue
                 const size_t tiles = stream_tiles(h->n);
                 PCL_REQUIRE(tiles <= 0x7FFFFFFFu, "too many particles for one launch");
@@ -1171,7 +1181,7 @@ int do_step_impl(pcl_compute* h, int* kind)
             a.n = h->n;
             a.partials = h->d_partials;
             a.hist = h->d_hist;
-            a.hist_groups = pcl::kCursorGroups;
+            a.hist_groups = groups;
             const float* packed = nullptr;
             if (int rc = current_field3(h, &packed)) return rc;
             a.field3 = packed;
@@ -1212,7 +1222,7 @@ int do_step_impl(pcl_compute* h, int* kind)
             else              rc = nt ? launch_stream<false, true>(h, a, U, T, grid, lds, count) : launch_stream<false, false>(h, a, U, T, grid, lds, count);
             if (rc) return rc;
             h->hist_valid = count;
-            if (count) h->hist_tiles = T;
+            if (count) { h->hist_tiles = T; h->hist_groups = groups; }
             if (count) *kind = PCL_STEP_STREAM_COUNT;
             if (count && a.runs) {
                 PCL_HIP_TRY(hipMemcpyAsync(h->h_runs, h->d_runs, pcl::kRunSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));

@@ -41,14 +41,17 @@ __device__ unsigned long long phase_clocks[256][24];
 #endif
 
 constexpr uint32_t kMaxReorderBins = 8192;
-// Every bin's counter and cursor exist kCursorGroups times, one per residue of the tile index:
-// the tiles that run at the same time fall into the same few bins, and their reservations on
-// one address serialise.  Measured on the scatter step of 2^28 particles: 1 group 4.58 ms,
-// 2: 4.29, 4: 3.96, 8: 3.96, 16: 4.25, 64: 5.14 (more groups cut every bin's range into more
-// pieces, which shortens the contiguous runs the scatter writes and the order's locality).
+// Every bin's counter and cursor exist several times, one per residue of the tile index (a "cursor
+// group"): the tiles that run at the same time fall into the same few bins, and their reservations on
+// one address serialise.  More groups cut every bin's range into more pieces, which shortens the
+// contiguous runs the scatter writes and the order's locality.  Measured on the scatter step of 2^28
+// particles with 256-cell sort tiles (65536 particles per bin): 1 group 4.58 ms, 2: 4.29, 4: 3.96,
+// 8: 3.96, 16: 4.25, 64: 5.14; with the 512-cell tiles the library uses there now (131072 per bin):
+// 2: 4.43, 4: 4.05, 8: 3.65, 16: 3.92; at 2^25 particles (1024-cell tiles, 32768 per bin): 4: 0.520,
+// 8: 0.515, 16: 0.54 ms with the whole step best at 4.  The host picks 4 or 8 by particles per bin.
 // Counter of bin b for tile t: group t % groups (storage: counter_index); the scan runs in
 // bin-major order, so every bin still owns one contiguous range of slots.
-constexpr uint32_t kCursorGroups = 4;
+constexpr uint32_t kMaxCursorGroups = 8;
 
 // Where the counter (and cursor) of (bin, group) is stored: group-major, which puts the
 // groups of one bin into different cache lines.
@@ -59,7 +62,7 @@ __device__ __forceinline__ uint32_t counter_index(uint32_t bin, uint32_t group, 
 
 // Histogram of tile keys: one tile of kStreamThreads * 4 particles per block, LDS
 // counters, one global atomic add per non-empty bin into the counter of the
-// tile's group (see kCursorGroups; groups = 1 gives one counter per bin).
+// tile's group (see kMaxCursorGroups; groups = 1 gives one counter per bin).
 __global__ __launch_bounds__(kStreamThreads) void reorder_count_kernel(
     StateSoA s, unsigned long long n, StepUniforms U, TileMap T, uint32_t* __restrict__ hist, uint32_t groups)
 {
