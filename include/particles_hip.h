@@ -472,6 +472,16 @@ int pcl_launch_geometry(const pcl_compute* h, uint32_t* grid_blocks,
 int pcl_launch_residency(const pcl_compute* h, uint32_t* intended_blocks_per_cu,
                          uint32_t* granted_blocks_per_cu);
 
+/* The cell-binned pair term (pcl_set_pair_mode) has two sweeps with the same
+ * results: one particle per lane with its own candidate ranges, or one wave per
+ * 64 slots with the candidates shared through LDS, which wins where the cut-off
+ * cells are crowded.  The library picks by the particles per occupied cell that
+ * the cell sort of two steps earlier counted.  *shared_sweep: 1 when the last
+ * binned step ran the shared sweep; *cells_occupied: the latest count read (0:
+ * none yet).  No counterpart in the reference (src/compute.wgsl:115-144 visits
+ * every pair). */
+int pcl_pair_sweep_info(const pcl_compute* h, uint32_t* shared_sweep, uint32_t* cells_occupied);
+
 /* Tuning knobs for measurements (0 keeps the built-in defaults; results never
  * depend on them).  grid_blocks caps the grid of the streaming kernel (the
  * blocks then stride over the tiles).  variant is a bit set:
@@ -493,6 +503,8 @@ int pcl_launch_residency(const pcl_compute* h, uint32_t* intended_blocks_per_cu,
  *   0x4      the scalar path of the streaming kernels only (full divisions) instead of the packed one
  *   0x100    plain streaming step: runs of 128 tiles dealt so that each XCD takes 16 consecutive ones (automatic
  *            from 3 * 2^23 to 2^26 particles in tile order with at most 40 per field cell), 0x400: never
+ *   0x800000 / 0x80000000  cell-binned pair term: always the sweep with one particle per lane / always the sweep with
+ *            the candidates shared by a wave (automatic: by the particles per occupied cut-off cell)
  *   0x200    particles in caller order are sorted once instead of twice before their first step
  *   0x40000  tests only: the next refresh of the particle order scatters with other keys than its
  *            histogram counted, which the kernel reports as PCL_ERR_DEVICE (the state is then unusable) */

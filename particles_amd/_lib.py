@@ -92,6 +92,7 @@ SIGNATURES = {
     "pcl_diagnostics_device_noalloc": (_i, [_vp, _vp]),
     "pcl_debug_cell_indices": (_i, [_vp, _vp, _sz, _sz]),
     "pcl_debug_pair_cells": (_i, [_vp, _vp, _vp, _sz, C.POINTER(_u32), C.POINTER(_u32)]),
+    "pcl_pair_sweep_info": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
     "pcl_debug_slot_order": (_i, [_vp, _vp, _sz]),
     "pcl_debug_state_checksum": (_i, [_vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "pcl_set_stream": (_i, [_vp, _vp]),

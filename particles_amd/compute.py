@@ -318,6 +318,12 @@ class Compute:
                                                   C.byref(per_axis), C.byref(reach)))
         return cells, bin_end[: per_axis.value ** 3], per_axis.value, reach.value
 
+    def pair_sweep_info(self):
+        """Which sweep the last cell-binned pair step ran, and the occupied cut-off cells it was chosen from."""
+        shared, cells = C.c_uint32(), C.c_uint32()
+        _lib.check(self._lib.pcl_pair_sweep_info(self._h, C.byref(shared), C.byref(cells)))
+        return {"shared_sweep": bool(shared.value), "cells_occupied": int(cells.value)}
+
     def debug_state_checksum(self, first_global_index=0):
         """(sum, xor) over all particles of a 64-bit mix of (global index, state bits, type): independent of
         the order of the particles in memory; the words of index ranges combine (sum mod 2^64, xor) to

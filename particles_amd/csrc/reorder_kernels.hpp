@@ -592,17 +592,32 @@ __global__ __launch_bounds__(kBlockThreads) void cell_key_kernel(
 }
 
 // bin_end[b] = number of sorted keys <= b (one past the last slot of cell b).
+// occupied[slot] (may be null) is raised by the number of cells that hold at least one particle:
+// what the host sizes up the cells' population with when it picks the sweep (see step_pairs_binned_wave_kernel).
 __global__ __launch_bounds__(kBlockThreads) void cell_end_kernel(
-    const uint32_t* __restrict__ sorted_key, unsigned long long n, uint32_t n_bins, uint32_t* __restrict__ bin_end)
+    const uint32_t* __restrict__ sorted_key, unsigned long long n, uint32_t n_bins, uint32_t* __restrict__ bin_end,
+    uint32_t* __restrict__ occupied)
 {
+    __shared__ uint32_t end_of[kBlockThreads];
     const uint32_t b = blockIdx.x * kBlockThreads + threadIdx.x;
-    if (b >= n_bins) return;
-    unsigned long long lo = 0, hi = n;   // first position whose key is > b
-    while (lo < hi) {
-        const unsigned long long mid = lo + (hi - lo) / 2;
-        if (sorted_key[mid] <= b) lo = mid + 1; else hi = mid;
-    }
-    bin_end[b] = (uint32_t)lo;
+    auto keys_up_to = [&](uint32_t bin) -> uint32_t {   // first position whose key is > bin
+        unsigned long long lo = 0, hi = n;
+        while (lo < hi) {
+            const unsigned long long mid = lo + (hi - lo) / 2;
+            if (sorted_key[mid] <= bin) lo = mid + 1; else hi = mid;
+        }
+        return (uint32_t)lo;
+    };
+    const uint32_t end = b < n_bins ? keys_up_to(b) : 0u;
+    if (b < n_bins) bin_end[b] = end;
+    if (!occupied) return;
+    end_of[threadIdx.x] = end;
+    __syncthreads();
+    uint32_t before = 0u;   // the end of the cell below
+    if (threadIdx.x) before = end_of[threadIdx.x - 1];
+    else if (b && b < n_bins) before = keys_up_to(b - 1u);
+    const unsigned long long holds = __builtin_amdgcn_ballot_w64(b < n_bins && end > before);
+    if ((threadIdx.x & 63u) == 0u && holds) atomicAdd(occupied, (uint32_t)__popcll(holds));
 }
 
 // dst[slot] = src[from[slot]]: `from` holds the caller index of every sorted slot

@@ -1111,6 +1111,118 @@ __global__ __launch_bounds__(kBlockThreads) void step_pairs_binned_kernel(
     if (DIAG) block_reduce_store(acc, a.partials + blockIdx.x);
 }
 
+// The same cell-binned pair term with the candidates shared by a whole wave.  One wave (a block of 64
+// threads) owns 64 consecutive slots of the cell-sorted order, i.e. the particles of one or two cells of
+// one (x, y) column (rarely of two columns: then the columns are taken one after the other with the other
+// column's lanes idle).  For every neighbour column the wave sweeps ONE slot range, the union of its lanes'
+// ranges (cells zmin - R .. zmax + R of that column), staged 64 candidates at a time in LDS and swept with
+// sweep_candidates: the skip tests of wgsl:120-131 for all 64 candidates first, then the force expression
+// for each lane's survivors only.  Where step_pairs_binned_kernel pays the force expression once per
+// candidate whenever ANY lane accepts it (always, with 64 lanes), a wave here pays it
+// max-over-lanes(survivors) times per 64 candidates.  A candidate outside a lane's own neighbourhood is
+// further away than the cut-off and fails the skip test, so every lane adds the same terms in the same
+// order (columns in (dx, dy) order, slots ascending) as in step_pairs_binned_kernel.
+template <bool DIAG>
+__global__ __launch_bounds__(64) void step_pairs_binned_wave_kernel(
+    PairArgs a, StepUniforms U, TileMap C, const uint32_t* __restrict__ bin_end)
+{
+    __shared__ f32x4 tile[64];
+    __shared__ float polys[25 * 8];
+    for (int k = threadIdx.x; k < 25 * 8; k += 64)
+        polys[k] = a.params->polys[k / 8][k % 8];
+    __syncthreads();
+    const float exponent = a.params->distance_exponent;
+
+    const unsigned long long i = (unsigned long long)blockIdx.x * 64ull + threadIdx.x;
+    const bool live = i < a.n;
+    float x = 0.f, y = 0.f, z = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
+    uint32_t my_ty = 0u;
+    if (live) {
+        x = a.src[0][i]; y = a.src[1][i]; z = a.src[2][i];
+        vx = a.src[3][i]; vy = a.src[4][i]; vz = a.src[5][i];
+        my_ty = a.ty[i];
+    }
+    const float* my_polys = &polys[my_ty * 5u * 8u];
+    // this particle's cell, exactly as the sort keyed it (shifts are 0 in a cell map)
+    const float px = fminf(fmaxf(x, U.neg_slh), U.slh);
+    const float py = fminf(fmaxf(y, U.neg_slh), U.slh);
+    const float pz = fminf(fmaxf(z, U.neg_slh), U.slh);
+    uint32_t cx = (uint32_t)((px - U.neg_slh) * C.inv_cell[0]);
+    uint32_t cy = (uint32_t)((py - U.neg_slh) * C.inv_cell[1]);
+    uint32_t cz = (uint32_t)((pz - U.neg_slh) * C.inv_cell[2]);
+    cx = cx < C.max_ix[0] ? cx : C.max_ix[0];
+    cy = cy < C.max_ix[1] ? cy : C.max_ix[1];
+    cz = cz < C.max_ix[2] ? cz : C.max_ix[2];
+    const int R = (int)C.reach;
+    auto axis_gap = [&](float p, int cell, uint32_t last) -> float {   // see step_pairs_binned_kernel
+        const float lo = cell == 0 ? -INFINITY : U.neg_slh + (float)cell * C.cell_len;
+        const float hi = cell == (int)last ? INFINITY : U.neg_slh + (float)(cell + 1) * C.cell_len;
+        const float gap = fmaxf(fmaxf(lo - p, p - hi), 0.0f);
+        return fmaxf(gap - 0.001f * C.cell_len, 0.0f);
+    };
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(live);
+    while (todo) {   // wave-uniform: one trip per (x, y) column present among the lanes
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t CX = (uint32_t)__builtin_amdgcn_readlane((int)cx, leader);
+        const uint32_t CY = (uint32_t)__builtin_amdgcn_readlane((int)cy, leader);
+        const bool mine = live && cx == CX && cy == CY;
+        const unsigned long long members = __builtin_amdgcn_ballot_w64(mine);
+        todo &= ~members;
+        // the slots are sorted z-fastest: the first member holds the lowest cell of the column, the last the highest
+        const uint32_t zmin = (uint32_t)__builtin_amdgcn_readlane((int)cz, __builtin_ctzll(members));
+        const uint32_t zmax = (uint32_t)__builtin_amdgcn_readlane((int)cz, 63 - __builtin_clzll(members));
+        const uint32_t z0 = zmin > (uint32_t)R ? zmin - (uint32_t)R : 0u;
+        const uint32_t z1 = zmax + (uint32_t)R < C.max_ix[2] ? zmax + (uint32_t)R : C.max_ix[2];
+        for (int dx = -R; dx <= R; ++dx) {
+            const int X = (int)CX + dx;
+            if (X < 0 || X > (int)C.max_ix[0]) continue;
+            const float gx = axis_gap(x, X, C.max_ix[0]);
+            for (int dy = -R; dy <= R; ++dy) {
+                const int Y = (int)CY + dy;
+                if (Y < 0 || Y > (int)C.max_ix[1]) continue;
+                const float gy = axis_gap(y, Y, C.max_ix[1]);
+                const bool reach = mine && !(gx * gx + gy * gy >= a.s_far);   // some cell of this column may be within the cut-off
+                if (__builtin_amdgcn_ballot_w64(reach) == 0ull) continue;
+                const uint32_t b0 = ((uint32_t)X * C.nty + (uint32_t)Y) * C.ntz + z0;
+                const uint32_t b1 = b0 + (z1 - z0);
+                const uint32_t j0 = b0 ? bin_end[b0 - 1u] : 0u;
+                const uint32_t j1 = bin_end[b1];
+                auto candidate = [&](uint32_t j) -> f32x4 {
+                    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                    if (j < j1) {
+                        t.x = a.src[0][j]; t.y = a.src[1][j]; t.z = a.src[2][j];
+                        t.w = __uint_as_float((uint32_t)a.ty[j]);
+                    }
+                    return t;
+                };
+                f32x4 next = candidate(j0 + threadIdx.x);
+                for (uint32_t base = j0; base < j1; base += 64u) {
+                    __syncthreads();   // the previous tile has been swept
+                    tile[threadIdx.x] = next;
+                    __syncthreads();
+                    next = candidate(base + 64u + threadIdx.x);   // in flight during the sweep
+                    const int cnt = j1 - base < 64u ? (int)(j1 - base) : 64;
+                    sweep_candidates(tile, cnt, reach, x, y, z, a.s_near, a.s_far, exponent, U, my_polys, ax, ay, az);
+                }
+            }
+        }
+    }
+
+    DiagAcc acc;
+    if (DIAG) acc.init();
+    if (live) {
+        const float m = mass_of(U, my_ty);
+        const f32x4 f = a.field[cell_index(U, x, y, z)];
+        integrate(U, f.x, f.y, f.z, m, ax, ay, az, x, y, z, vx, vy, vz);
+        a.dst[0][i] = x; a.dst[1][i] = y; a.dst[2][i] = z;
+        a.dst[3][i] = vx; a.dst[4][i] = vy; a.dst[5][i] = vz;
+        if (DIAG) acc.add(m, x, y, z, vx, vy, vz);
+    }
+    if (DIAG) block_reduce_store<64>(acc, a.partials + blockIdx.x);
+}
+
 // ------------------------------------------------- standalone diagnostics K3
 
 __global__ __launch_bounds__(kBlockThreads) void diag_reduce_kernel(

@@ -732,6 +732,51 @@ def test_cell_sort_is_the_stable_sort_by_cell(oracle, n, per_axis_cutoff):
         assert np.array_equal(bin_end, np.cumsum(np.bincount(want, minlength=per_axis ** 3)).astype(np.uint32))
 
 
+@pytest.mark.parametrize("n,cutoff,extent,exponent", [
+    (40000, 0.3, 2.0, 0.0), (40000, 1.0, 2.0, 0.0), (70001, 1.0, 20.0, 0.0), (9000, 2.5, 24.0, -1.0), (300000, 0.9, 20.0, 0.0), (129, 30.0, 20.0, 0.5)])
+def test_the_two_sweeps_of_the_binned_pair_term_agree_bit_for_bit(oracle, n, cutoff, extent, exponent):
+    """The sweep with one particle per lane and the sweep with the candidates shared by a wave add the same terms in
+    the same order: a start-up cluster, uniform sets with one- and two-cell reach, particles beyond the box, one
+    cell, ragged last waves; three steps each, every bit equal."""
+    sp = pair_params(exponent)
+    sp.cut_off_distance = cutoff
+    g = sp.new_force_grid_centered().get_force_vectors()
+    p = oracle.synth_particles(n, seed=n + 3, pos_extent=extent, vel_extent=4.0)
+    states = []
+    for variant in (0x800000, 0x80000000):
+        with pa.Compute.new(p, g) as c:
+            c.update_sim_params(sp)
+            c.set_pair_mode(2)
+            c.set_tuning(0, variant)
+            for _ in range(3):
+                c.compute()
+            assert c.pair_sweep_info()["shared_sweep"] == (variant == 0x80000000)
+            states.append(c.read_particles())
+    assert_particles_bit_equal(states[1], states[0], "shared sweep against per-lane sweep")
+
+
+def test_the_binned_sweep_follows_the_population_of_the_cells(oracle):
+    """A start-up cluster (40000 particles in a 2-unit cube of the 20-unit box: a few dozen crowded cells) moves to
+    the shared sweep as soon as the count of occupied cells of the first sort is in (step 3), a uniform set of the
+    same size (5 particles per cell) stays with one particle per lane."""
+    sp = pair_params(0.0)
+    sp.cut_off_distance = 0.5
+    g = sp.new_force_grid_centered().get_force_vectors()
+    for extent, crowded in ((2.0, True), (20.0, False)):
+        p = oracle.synth_particles(40000, seed=8, pos_extent=extent, vel_extent=1.0)
+        with pa.Compute.new(p, g) as c:
+            c.update_sim_params(sp)
+            c.set_pair_mode(2)
+            used = []
+            for _ in range(5):
+                c.compute()
+                used.append(c.pair_sweep_info()["shared_sweep"])
+            info = c.pair_sweep_info()
+            assert used[:2] == [False, False] and used[2:] == [crowded] * 3, (extent, used, info)
+            assert 0 < info["cells_occupied"] <= 20 ** 3
+            assert (40000 // info["cells_occupied"] >= 512) == crowded
+
+
 def _with_w1(p):
     q = p.copy()
     q["pos"][:, 3] = 1.0
