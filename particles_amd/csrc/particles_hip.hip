@@ -1299,6 +1299,7 @@ int do_step_impl(pcl_compute* h, int* kind)
         a.s_near = smallest_square_with([](float len) { return !(len < 0.001f); });
         const float cut = h->params.cut_off_distance;
         a.s_far = smallest_square_with([cut](float len) { return len > cut; });
+        if (std::isnan(a.s_far)) a.s_far = INFINITY;   // no distance is too far: see no_candidate() in step_kernels.hpp
         if (!per_lane) {
             if (h->step_diag)
                 hipLaunchKernelGGL((pcl::step_pairs_binned_wave_kernel<true>), dim3(grid), dim3(64), 0, h->stream, a, U, C, bin_end);
@@ -1341,6 +1342,7 @@ int do_step_impl(pcl_compute* h, int* kind)
         a.s_near = smallest_square_with([](float len) { return !(len < 0.001f); });
         const float cut = h->params.cut_off_distance;
         a.s_far = smallest_square_with([cut](float len) { return len > cut; });
+        if (std::isnan(a.s_far)) a.s_far = INFINITY;   // no distance is too far: see no_candidate() in step_kernels.hpp
         a.sources = h->ext_sources;
         a.n_sources = h->n_ext_sources;
         if (gathered) {

@@ -904,49 +904,46 @@ __device__ __forceinline__ void pair_term(const f32x4 o, float x, float y, float
     tz = ((__fdiv_rn(dz, len) * pv) * m2) * df;
 }
 
-// One particle (this lane) against `cnt` staged candidates (x, y, z, type) in
-// LDS, in candidate order.  Two passes per 64 candidates: a cheap pass applies
-// the skip tests of wgsl:120-131 on the squared distance and records the
-// survivors in a 64-bit lane mask; a second pass evaluates wgsl:132-139 for the
-// survivors only, lowest bit first.  A wave therefore runs the expensive part
-// max-over-lanes(survivors) times instead of once per candidate whenever any
-// lane survives, and each lane still adds its terms in candidate order.  The
-// particle itself is among the candidates and drops out with s = 0 < s_near.
-template <bool PADDED = false>
-__device__ __forceinline__ void sweep_candidates(const f32x4* tile, int cnt, bool live, float x, float y, float z,
+// One particle (this lane) against a tile of 64 staged candidates (x, y, z, type) in LDS, in candidate
+// order.  Two passes: a cheap pass applies the skip tests of wgsl:120-131 on the squared distance to all 64
+// and records the survivors in two 32-bit lane masks (candidate k < 32 is bit 31 - k of the first, so that
+// a mask grows by one shift-and-or per candidate and no shift amount depends on k); a second pass
+// evaluates wgsl:132-139 for the survivors only, lowest candidate first.  A wave therefore runs the
+// expensive part max-over-lanes(survivors) times instead of once per candidate whenever any lane survives,
+// and each lane still adds its terms in candidate order.  The particle itself is among the candidates and
+// drops out with s = 0 < s_near.  Entries past the end of the candidates hold no_candidate(): a position
+// whose squared distance from anything overflows to +inf (also from a particle at +-inf, where an infinite
+// sentinel would give NaN), which fails the far test s >= s_far for every s_far the host passes (with no far
+// cut-off at all -- an infinite or NaN cut_off_distance -- the host passes +inf, so that the one pair this
+// deviates on is a real pair whose squared distance overflows fp32).
+__device__ __forceinline__ f32x4 no_candidate() { return f32x4{3.4028234663852886e38f, 0.0f, 0.0f, 0.0f}; }
+
+__device__ __forceinline__ void sweep_candidates(const f32x4* tile, bool live, float x, float y, float z,
                                                  float s_near, float s_far, float exponent, const StepUniforms& U,
                                                  const float* my_polys, float& ax, float& ay, float& az)
 {
-    for (int sb = 0; sb < cnt; sb += 64) {
-        const int m = cnt - sb < 64 ? cnt - sb : 64;   // wave-uniform
-        unsigned long long mask = 0ull;
-        if (live) {
-            if (m == 64) {
+    uint32_t mask[2] = {0u, 0u};
+    if (live) {
 #pragma unroll
-                for (int k = 0; k < 64; ++k) {
-                    const f32x4 o = tile[sb + k];
-                    const float dx = o.x - x, dy = o.y - y, dz = o.z - z;
-                    const float s = (dx * dx + dy * dy) + dz * dz;
-                    bool keep = !(s < s_near) && !(s >= s_far);
-                    if (PADDED) keep = keep && __float_as_uint(o.w) < 5u;
-                    mask |= (unsigned long long)keep << k;
-                }
-            } else {
-                for (int k = 0; k < m; ++k) {
-                    const f32x4 o = tile[sb + k];
-                    const float dx = o.x - x, dy = o.y - y, dz = o.z - z;
-                    const float s = (dx * dx + dy * dy) + dz * dz;
-                    bool keep = !(s < s_near) && !(s >= s_far);
-                    if (PADDED) keep = keep && __float_as_uint(o.w) < 5u;
-                    mask |= (unsigned long long)keep << k;
-                }
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {
+                const f32x4 o = tile[32 * h + k];
+                const float dx = o.x - x, dy = o.y - y, dz = o.z - z;
+                const float s = (dx * dx + dy * dy) + dz * dz;
+                const bool keep = !(s < s_near) && !(s >= s_far);
+                mask[h] = (mask[h] << 1) | (keep ? 1u : 0u);
             }
         }
-        while (mask) {
-            const int k = __builtin_ctzll(mask);
-            mask &= mask - 1ull;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        uint32_t m = mask[h];
+        while (m) {
+            const int k = __builtin_clz(m);
+            m &= ~(0x80000000u >> k);
             float tx, ty, tz;
-            pair_term(tile[sb + k], x, y, z, exponent, U, my_polys, tx, ty, tz);
+            pair_term(tile[32 * h + k], x, y, z, exponent, U, my_polys, tx, ty, tz);
             ax = ax + tx; ay = ay + ty; az = az + tz;
         }
     }
@@ -991,10 +988,11 @@ __global__ __launch_bounds__(PB) void step_pairs_kernel(PairArgs a, StepUniforms
     for (unsigned long long base = 0; base < n_partners; base += PB) {
         __syncthreads();
         const unsigned long long j = base + threadIdx.x;
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        f32x4 t = no_candidate();
         if (j < n_partners) {
             if (GATHERED) {
                 t = a.sources[j];
+                if (__float_as_uint(t.w) >= 5u) t = no_candidate();   // padding between the ranks' ranges
             } else {
                 t.x = a.src[0][j]; t.y = a.src[1][j]; t.z = a.src[2][j];
                 t.w = __uint_as_float((uint32_t)a.ty[j]);
@@ -1002,9 +1000,10 @@ __global__ __launch_bounds__(PB) void step_pairs_kernel(PairArgs a, StepUniforms
         }
         tile[threadIdx.x] = t;
         __syncthreads();
-        const unsigned long long rem = n_partners - base;
-        const int cnt = rem < (unsigned long long)PB ? (int)rem : PB;
-        sweep_candidates<GATHERED>(tile, cnt, live, x, y, z, a.s_near, a.s_far, exponent, U, my_polys, ax, ay, az);
+#pragma unroll
+        for (int sub = 0; sub < PB; sub += 64)   // whole tiles of 64: the last ones end in no_candidate()
+            if (base + sub < n_partners)
+                sweep_candidates(tile + sub, live, x, y, z, a.s_near, a.s_far, exponent, U, my_polys, ax, ay, az);
     }
 
     DiagAcc acc;
@@ -1190,7 +1189,7 @@ __global__ __launch_bounds__(64) void step_pairs_binned_wave_kernel(
                 const uint32_t j0 = b0 ? bin_end[b0 - 1u] : 0u;
                 const uint32_t j1 = bin_end[b1];
                 auto candidate = [&](uint32_t j) -> f32x4 {
-                    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 t = no_candidate();
                     if (j < j1) {
                         t.x = a.src[0][j]; t.y = a.src[1][j]; t.z = a.src[2][j];
                         t.w = __uint_as_float((uint32_t)a.ty[j]);
@@ -1203,8 +1202,7 @@ __global__ __launch_bounds__(64) void step_pairs_binned_wave_kernel(
                     tile[threadIdx.x] = next;
                     __syncthreads();
                     next = candidate(base + 64u + threadIdx.x);   // in flight during the sweep
-                    const int cnt = j1 - base < 64u ? (int)(j1 - base) : 64;
-                    sweep_candidates(tile, cnt, reach, x, y, z, a.s_near, a.s_far, exponent, U, my_polys, ax, ay, az);
+                    sweep_candidates(tile, reach, x, y, z, a.s_near, a.s_far, exponent, U, my_polys, ax, ay, az);
                 }
             }
         }
