@@ -97,6 +97,8 @@ extern "C" {
     fn pcl_comm_diagnostics_read(h: *mut PclCompute, out: *mut Diagnostics) -> c_int;
     fn pcl_launch_residency(h: *const PclCompute, intended_blocks_per_cu: *mut u32, granted_blocks_per_cu: *mut u32) -> c_int;
     fn pcl_device_pci_bus_id(h: *const PclCompute, out: *mut c_char, capacity: usize) -> c_int;
+    fn pcl_pair_sweep_info(h: *const PclCompute, shared_sweep: *mut u32, cells_occupied: *mut u32) -> c_int;
+    fn pcl_debug_state_checksum(h: *mut PclCompute, first_global_index: u64, sum: *mut u64, xor_of_all: *mut u64) -> c_int;
 }
 
 impl Poly7 {
@@ -348,6 +350,22 @@ impl Compute {
         let (mut intended, mut granted) = (0u32, 0u32);
         check(unsafe { pcl_launch_residency(self.handle, &mut intended, &mut granted) });
         (intended, granted)
+    }
+
+    /// Which of the two (bit-identical) sweeps of the cell-binned pair term the last step ran -- `true`:
+    /// candidates shared by a wave -- and the count of occupied cut-off cells it was chosen from.
+    pub fn pair_sweep_info(&self) -> (bool, u32) {
+        let (mut shared, mut cells) = (0u32, 0u32);
+        check(unsafe { pcl_pair_sweep_info(self.handle, &mut shared, &mut cells) });
+        (shared != 0, cells)
+    }
+
+    /// Order-independent checksum (sum, xor) of the whole state; the words of index ranges, each taken
+    /// with its first global index, combine to those of one handle holding the whole set.
+    pub fn state_checksum(&mut self, first_global_index: u64) -> (u64, u64) {
+        let (mut sum, mut xor) = (0u64, 0u64);
+        check(unsafe { pcl_debug_state_checksum(self.handle, first_global_index, &mut sum, &mut xor) });
+        (sum, xor)
     }
 
     /// PCI bus id of the handle's GPU ("0000:c1:00.0"), to tell devices apart across processes.
