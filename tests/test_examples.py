@@ -47,3 +47,14 @@ def test_examples_print_the_oracles_default_scene(tmp_path, oracle):
         assert count == 1000 and abs(ke - want_ke) <= 1e-8 * want_ke
         for row, i in zip(rows, (0, 999)):     # %.9g round-trips fp32 exactly
             assert np.array_equal(row[:3], want["pos"][i, :3]) and np.array_equal(row[3:], want["vel"][i, :3]), text
+
+
+@pytest.mark.gpu
+def test_native_walk_over_the_whole_c_abi():
+    """tests/cpp/api_walk (built by `make`): every entry point of include/particles_hip.h called from
+    a native program, status codes checked; `make sanitize` builds the copy whose host code runs under
+    AddressSanitizer and UndefinedBehaviorSanitizer."""
+    exe = os.path.join(ROOT, "tests", "cpp", "api_walk")
+    assert os.path.exists(exe), "tests/cpp/api_walk is not built (make)"
+    done = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0 and "api_walk ok" in done.stdout, done.stdout + done.stderr
