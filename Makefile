@@ -14,6 +14,7 @@ COMM_SRC  := particles_amd/csrc/particles_comm.hip
 COMM_OBJ  := build/particles_comm.o
 
 CPPTEST   := tests/cpp/compute_wrapper_test
+APIWALK   := tests/cpp/api_walk
 
 FAKE_RCCL := tests/fake_rccl/libfake_rccl.so
 
@@ -55,22 +56,26 @@ $(CPPTEST): tests/cpp/compute_wrapper_test.cpp include/particles_compute.hpp inc
 	g++ -O2 -std=c++17 -Wall -Wextra -Iinclude -o $@ $< -Lparticles_amd -lparticles_hip -Wl,-rpath,'$$ORIGIN/../../particles_amd' -Wl,-rpath-link,/opt/rocm/lib
 
 # The whole C ABI walked once by a native program (status codes only; results are the Python tests' business).
-APIWALK   := tests/cpp/api_walk
 $(APIWALK): tests/cpp/api_walk.cpp include/particles_hip.h $(LIB)
-	g++ -O1 -std=c++17 -Wall -Wextra -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include -o $@ $< -Lparticles_amd -lparticles_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../../particles_amd' -Wl,-rpath,/opt/rocm/lib
+	g++ -O1 -std=c++17 -Wall -Wextra -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include -o $@ $< -Lparticles_amd -lparticles_hip -L/opt/rocm/lib -lamdhip64 -lpthread -Wl,-rpath,'$$ORIGIN/../../particles_amd' -Wl,-rpath,/opt/rocm/lib
 
-# The same program and a copy of the library with the HOST code under AddressSanitizer and
-# UndefinedBehaviorSanitizer (device code is not instrumented): build/sanitize/, run on a GPU box as
-#   ASAN_OPTIONS=detect_leaks=0 build/sanitize/api_walk
-SAN       := -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -fno-sanitize-recover=undefined -Xarch_host -fno-omit-frame-pointer -g
+# The same program and a copy of the library with the HOST code under sanitizers (device code is not
+# instrumented): by default AddressSanitizer + UndefinedBehaviorSanitizer into build/sanitize/; run on a GPU box as
+#   ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 build/sanitize/api_walk
+# `make sanitize SANKIND=thread SANDIR=build/tsan` builds the ThreadSanitizer copies the same way.
+SANKIND   ?= address,undefined
+SANDIR    ?= build/sanitize
+SANHOST   := -fsanitize=$(SANKIND) -fno-sanitize-recover=all -fno-omit-frame-pointer -g
+SAN       := $(foreach f,$(SANHOST),-Xarch_host $(f))
+CLANGXX   := /opt/rocm/lib/llvm/bin/clang++
 sanitize: $(SRC) $(SORT_SRC) $(COMM_SRC) $(HDRS) particles_amd/csrc/authoring.cpp tests/cpp/api_walk.cpp
-	mkdir -p build/sanitize
-	$(HIPCC) $(HIPFLAGS) $(SAN) -c -o build/sanitize/particles_hip.o $(SRC)
-	$(HIPCC) $(HIPFLAGS) $(SAN) -Wno-unused-parameter -c -o build/sanitize/pair_sort.o $(SORT_SRC)
-	$(HIPCC) $(HIPFLAGS) $(SAN) -c -o build/sanitize/particles_comm.o $(COMM_SRC)
-	/opt/rocm/lib/llvm/bin/clang++ -O1 -g -std=c++17 -ffp-contract=off -fPIC -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -Iinclude -c -o build/sanitize/authoring.o particles_amd/csrc/authoring.cpp
-	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -fsanitize=address,undefined -shared-libsan -o build/sanitize/libparticles_hip.so build/sanitize/particles_hip.o build/sanitize/pair_sort.o build/sanitize/particles_comm.o build/sanitize/authoring.o -ldl
-	/opt/rocm/lib/llvm/bin/clang++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=undefined -shared-libsan -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include -o build/sanitize/api_walk tests/cpp/api_walk.cpp -Lbuild/sanitize -lparticles_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,$$(dirname $$(/opt/rocm/lib/llvm/bin/clang++ -print-file-name=libclang_rt.asan-x86_64.so))
+	mkdir -p $(SANDIR)
+	$(HIPCC) $(HIPFLAGS) $(SAN) -c -o $(SANDIR)/particles_hip.o $(SRC)
+	$(HIPCC) $(HIPFLAGS) $(SAN) -Wno-unused-parameter -c -o $(SANDIR)/pair_sort.o $(SORT_SRC)
+	$(HIPCC) $(HIPFLAGS) $(SAN) -c -o $(SANDIR)/particles_comm.o $(COMM_SRC)
+	$(CLANGXX) -O1 -std=c++17 -ffp-contract=off -fPIC $(SANHOST) -Iinclude -c -o $(SANDIR)/authoring.o particles_amd/csrc/authoring.cpp
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -fsanitize=$(SANKIND) -shared-libsan -o $(SANDIR)/libparticles_hip.so $(SANDIR)/particles_hip.o $(SANDIR)/pair_sort.o $(SANDIR)/particles_comm.o $(SANDIR)/authoring.o -ldl
+	$(CLANGXX) -O1 -std=c++17 $(SANHOST) -shared-libsan -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include -o $(SANDIR)/api_walk tests/cpp/api_walk.cpp -L$(SANDIR) -lparticles_hip -L/opt/rocm/lib -lamdhip64 -lpthread -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,$$(dirname $$($(CLANGXX) -print-file-name=libclang_rt.asan-x86_64.so))
 
 asm: $(SRC) $(HDRS)
 	mkdir -p build
@@ -78,7 +83,7 @@ asm: $(SRC) $(HDRS)
 
 clean:
 	rm -f $(LIB) $(CPPTEST) $(APIWALK) $(FAKE_RCCL)
-	rm -rf build/sanitize
+	rm -rf build/sanitize build/tsan
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle asm clean sanitize

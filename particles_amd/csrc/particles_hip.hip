@@ -18,6 +18,7 @@
 #include "handle_access.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -614,14 +615,11 @@ int launch_plain_shaped(pcl_compute* h, const pcl::StreamArgs& a, const pcl::Ste
     h->residency_intended = cap;
     h->residency_granted = granted;
     if (cap != 0 && granted != cap) {
-        static bool reported = false;
+        static std::atomic<bool> reported{false};
         g_last_error = "the residency cap of the streaming step asked for " + std::to_string(cap) + " blocks of " +
                        std::to_string(BLOCK) + " threads per CU with " + std::to_string(pad) +
                        " bytes of dynamic LDS, the runtime grants " + std::to_string(granted) + ": launching without the cap";
-        if (!reported) {
-            std::fprintf(stderr, "particles_hip: %s\n", g_last_error.c_str());
-            reported = true;
-        }
+        if (!reported.exchange(true)) std::fprintf(stderr, "particles_hip: %s\n", g_last_error.c_str());
         pad = 0;
     }
     hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, false, false, BLOCK>), dim3((uint32_t)blocks), dim3(BLOCK),

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -409,6 +410,40 @@ void walk_authoring()
     FAILS(pcl_sim_params_force_grid(&sp, 1, reinterpret_cast<float(*)[4]>(field.data()), 999), PCL_ERR_OUT_OF_RANGE);
 }
 
+// "Different handles are independent": four threads, each with a handle of its own on the same GPU, make the
+// same calls at the same time; the same seed must give every thread the same state.
+void walk_threads(const std::vector<float>& field, size_t n_cells, const pcl_sim_params& sp)
+{
+    const int n_threads = 4;
+    std::vector<uint64_t> sums(n_threads, 0), xors(n_threads, 0);
+    std::vector<int> failed(n_threads, 0);
+    std::vector<std::thread> threads;
+    for (int t = 0; t < n_threads; ++t)
+        threads.emplace_back([&, t] {
+            pcl_compute* h = nullptr;
+            int bad = 0;
+            bad += pcl_create(nullptr, 0, as_cells(field), n_cells, 0, &h) != PCL_OK;
+            if (!h) { failed[t] = 1; return; }
+            bad += pcl_generate_particles(h, ((size_t)1 << 20) + 1, 77, 0, 20.0f, 10.0f) != PCL_OK;
+            bad += pcl_update_sim_params(h, &sp) != PCL_OK;
+            bad += pcl_enable_step_diagnostics(h, t & 1) != PCL_OK;
+            for (int s = 0; s < 50; ++s) bad += pcl_step(h) != PCL_OK;
+            bad += pcl_step_n(h, 20) != PCL_OK;
+            pcl_diagnostics d;
+            bad += pcl_diagnostics_read(h, &d) != PCL_OK;
+            bad += pcl_debug_state_checksum(h, 0, &sums[t], &xors[t]) != PCL_OK;
+            bad += pcl_step(nullptr) != PCL_ERR_INVALID;            // the error text is per thread
+            bad += std::strlen(pcl_last_error()) == 0;
+            bad += pcl_destroy(h) != PCL_OK;
+            failed[t] = bad;
+        });
+    for (std::thread& th : threads) th.join();
+    for (int t = 0; t < n_threads; ++t) {
+        if (failed[t]) { std::fprintf(stderr, "thread %d: %d calls failed\n", t, failed[t]); ++g_failures; }
+        if (sums[t] != sums[0] || xors[t] != xors[0]) { std::fprintf(stderr, "thread %d ended in another state than thread 0\n", t); ++g_failures; }
+    }
+}
+
 }  // namespace
 
 int main()
@@ -445,6 +480,8 @@ int main()
     walk_comm(h, field, n_cells, sp);
     OK(pcl_destroy(h));
     walk_group(field, n_cells, sp);
+
+    walk_threads(field, n_cells, sp);
 
     // two handles alive at once, destroyed in the other order
     pcl_compute *a = nullptr, *b = nullptr;
