@@ -262,6 +262,28 @@ def test_numpy_restatement_agrees_pairs(oracle):
         assert np.allclose(got[f], want[f], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_numpy_restatement_agrees_over_the_gui_parameter_ranges(oracle, seed):
+    """The parameter domain of the reference's GUI (src/gui.rs:130-318; the generator of the GPU sweep in
+    test_gpu_random_params.py), field shapes from one cell to 64 per axis, time steps from 0 to 0.19, particles
+    beyond the bounding cube and speeds on both sides of the clamp: three steps, every one bit for bit
+    (every fourth seed with the pair term, exponent 0)."""
+    from test_gpu_random_params import random_case
+    rng = np.random.default_rng(7000 + seed)
+    pairs = seed % 4 == 3
+    sp, g = random_case(rng, pairs)
+    r = float(sp.bounding_volume_radius)
+    n = 300 if pairs else 2000
+    cur = oracle.synth_particles(n, seed=seed, pos_extent=(min(2.0 * r, 6.0) if pairs else 2.4 * r),
+                                 vel_extent=float(rng.choice([0.0, 1.0, 10.0, 400.0]))).view(pa.PARTICLE_DTYPE)
+    for step in range(3):
+        got, fgi = NP.step(sp, cur, g, exp_neg(sp.delta_t), pairs=pairs)
+        assert np.array_equal(fgi, oracle.cell_indices(sp, cur, g.shape[0]))
+        want = oracle.step(sp, cur, g, mode=oracle.MODE_ALWAYS_PAIRS if pairs else oracle.MODE_SKIP_INERT).view(pa.PARTICLE_DTYPE)
+        assert_particles_bit_equal(got, want, f"seed {seed} step {step}")
+        cur = want
+
+
 def test_synthetic_generator_distribution(oracle):
     """pos_extent*(u-0.5) with u in [0,1): the distribution of src/main.rs:41-48."""
     p = oracle.synth_particles(200000, seed=4, pos_extent=2.0, vel_extent=10.0)
