@@ -326,8 +326,14 @@ def run_case(args, ctx, *, scaling, n_total, diag_on, with_cpu_baseline):
     for _ in range(args.steps):
         one_step()
     region_ms = c.timer_stop() / max(1, args.steps)   # HIP events around the whole timed region
-    fence()
+    # This rank's clock stops when its own GPU is idle again; the closing barrier comes after it, and the
+    # MAX over ranks taken below is the job's time (every rank started from the same barrier).  A clock
+    # stopped behind the barrier would charge the steps a host round trip between N processes, which at
+    # 8 ranks is a tenth of a 20-step window of 2^25-particle steps.
+    sc.wait()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    fence()
     launch_ms, launch_kind = c.step_timing_read()
     reorders_timed = c.reorder_count - reorders0
     # the dominant kernel: the plain step kernel (streaming or pair), without the launches that
