@@ -551,7 +551,10 @@ int pcl_sim_params_force_grid(const pcl_sim_params* params, int centered, float 
  * term active, one ncclAllGather of 16 bytes per particle per step; with step
  * diagnostics on, one ncclGroupStart/End pair of all-reduces of the 48-byte
  * record per step.  Every collective runs on the handle's own stream, ordered
- * with its kernels.  RCCL is loaded at first use (dlopen; PCL_RCCL_LIBRARY
+ * with its kernels, except that per-step all-reduce: nothing in the next step
+ * needs its result, so it runs on a stream of the communicator's own, beside
+ * the following step (the ranks then wait for one another at most two steps
+ * apart instead of after every step).  RCCL is loaded at first use (dlopen; PCL_RCCL_LIBRARY
  * names the file when the default search is not wanted); without it these
  * calls return PCL_ERR_COMM and the rest of the library works.
  *
@@ -593,8 +596,10 @@ int pcl_comm_brush_mouse_moved(pcl_compute* h, const pcl_brush_input* in, int ro
  * active: all ranks exchange positions and types first (all-gather) and every
  * particle sums over all of them in global index order, which gives the bits
  * of one handle holding every particle under PCL_PAIRS_ALL.  Step diagnostics
- * enabled: also starts the all-reduce of the record (asynchronous; the result
- * is what pcl_comm_diagnostics_device points at).  No host synchronisation,
+ * enabled: also starts the all-reduce of the step's record, beside the steps
+ * that follow (the result is what pcl_comm_diagnostics_device points at; the
+ * calls that wait for the handle's stream wait for it too; steps of such a
+ * handle should all go through this call).  No host synchronisation,
  * except in the first step after pcl_comm_attach, after a call that replaced
  * the particle set (pcl_upload_particles[_soa], pcl_generate_particles) and
  * after a change of what a step exchanges (pair term active or inert, step
@@ -604,7 +609,11 @@ int pcl_comm_brush_mouse_moved(pcl_compute* h, const pcl_brush_input* in, int ro
  * differ.  All ranks must therefore replace their particle sets and change
  * these settings between the same two steps. */
 int pcl_comm_step(pcl_compute* h);
-/* Diagnostics of the latest state of ALL ranges, identical on every rank. */
+/* Diagnostics of the latest state of ALL ranges, identical on every rank:
+ * read back (a collective of its own, synchronises), or the device address of
+ * the record the latest pcl_comm_step with step diagnostics all-reduced, valid
+ * for work enqueued on the handle's stream AFTER this call (the call orders
+ * that stream behind the all-reduce; no host synchronisation). */
 int pcl_comm_diagnostics_read(pcl_compute* h, pcl_diagnostics* out);
 int pcl_comm_diagnostics_device(pcl_compute* h, const void** dev_record);
 

@@ -23,13 +23,19 @@ size_t cells_of(const pcl_compute* h);
 // Reduces the diagnostics of the latest state on the handle's stream (unless a fused per-step
 // result is current) and returns the device address of the 48-byte record.
 int diagnostics_on_device(pcl_compute* h, const void** dev_record);
+// Where the handle's reductions write the 48-byte record from now on (device memory of the caller's;
+// null: the handle's own record again).  The multi-GPU layer alternates between two records of its own,
+// so that a collective may still read one step's record while the next step writes the other.
+void set_diag_target(pcl_compute* h, void* dev_record);
 bool pair_term_active(const pcl_compute* h);              // the parameters' pair term is not provably zero
 bool step_diagnostics_enabled(const pcl_compute* h);
 // Goes up with every call that replaces the particle set (upload, SoA upload, generate), whether or
 // not the count changed: ranks that make the same calls see it change between the same two steps.
 uint64_t particles_epoch(const pcl_compute* h);
-// One slot for the multi-GPU layer's per-handle state; `release` runs in pcl_destroy.
-void set_comm(pcl_compute* h, void* comm, void (*release)(void*));
+// One slot for the multi-GPU layer's per-handle state; `release` runs in pcl_destroy, `sync` (may be
+// null) in every call that waits for the handle's stream, before that wait: the layer's own stream
+// carries work that the handle's stream does not wait for.
+void set_comm(pcl_compute* h, void* comm, void (*release)(void*), int (*sync)(void*) = nullptr);
 void* comm_of(const pcl_compute* h);
 
 }  // namespace pcl_internal

@@ -153,6 +153,18 @@ struct Comm {
     bool agreed_pairs = false, agreed_diag = false;
     size_t agreed_cap = 0;
     pcl_diagnostics* d_global = nullptr;     // the all-reduced record
+    // The per-step all-reduce of the diagnostics runs beside the next step, on a stream of its own:
+    // nothing on the handle's stream needs its result.  Steps write their record alternately into two
+    // slots (pcl_internal::set_diag_target), the side stream waits for the step, all-reduces its slot
+    // into d_global and marks the slot free again; a step waits for the all-reduce that last read the
+    // slot it is about to write, which was issued two steps earlier.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_ready[2] = {nullptr, nullptr};   // handle's stream: the slot holds the step's record
+    hipEvent_t ev_done[2] = {nullptr, nullptr};    // side stream: the all-reduce of the slot has finished
+    pcl_diagnostics* d_slot = nullptr;             // two records
+    int next_slot = 0;                             // the slot the next step with diagnostics writes
+    int armed_slot = -1;                           // the slot the handle currently writes its record into
+    int pending_slot = -1;                         // slot of the latest all-reduce issued on the side stream
 };
 
 Comm* comm_of(pcl_compute* h) { return h ? static_cast<Comm*>(pcl_internal::comm_of(h)) : nullptr; }
@@ -161,7 +173,14 @@ void release_comm(void* p)
 {
     Comm* c = static_cast<Comm*>(p);
     if (!c) return;
+    if (c->side) (void)hipStreamSynchronize(c->side);
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    for (int k = 0; k < 2; ++k) {
+        if (c->ev_ready[k]) (void)hipEventDestroy(c->ev_ready[k]);
+        if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
+    }
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->d_slot) (void)hipFree(c->d_slot);
     if (c->d_record) (void)hipFree(c->d_record);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_pair_send) (void)hipFree(c->d_pair_send);
@@ -172,6 +191,21 @@ void release_comm(void* p)
     delete c;
 }
 
+// What a call that waits for the handle's stream waits for first: the side stream's all-reduces.
+int sync_comm(void* p)
+{
+    Comm* c = static_cast<Comm*>(p);
+    if (c && c->side && c->pending_slot >= 0) PCL_HIP_TRY(hipStreamSynchronize(c->side));
+    return PCL_OK;
+}
+
+// Work enqueued on the handle's stream from here on runs after the latest all-reduce of the side stream.
+int order_after_side(pcl_compute* h, Comm* c)
+{
+    if (c->pending_slot >= 0) PCL_HIP_TRY(hipStreamWaitEvent(pcl_internal::stream_of(h), c->ev_done[c->pending_slot], 0));
+    return PCL_OK;
+}
+
 // Adopts `comm` (already initialised for h's device) as h's communicator.
 int adopt(pcl_compute* h, ncclComm_t comm, int rank, int world)
 {
@@ -180,8 +214,14 @@ int adopt(pcl_compute* h, ncclComm_t comm, int rank, int world)
     c->comm = comm;
     c->rank = rank;
     c->world = world;
-    pcl_internal::set_comm(h, c, release_comm);   // from here on pcl_destroy releases it
+    pcl_internal::set_comm(h, c, release_comm, sync_comm);   // from here on pcl_destroy releases it
     if (int rc = pcl_internal::make_current(h)) return rc;
+    PCL_HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+        PCL_HIP_TRY(hipEventCreateWithFlags(&c->ev_ready[k], hipEventDisableTiming));
+        PCL_HIP_TRY(hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
+    }
+    PCL_HIP_TRY(hipMalloc((void**)&c->d_slot, 2 * sizeof(pcl_diagnostics)));
     PCL_HIP_TRY(hipMalloc(&c->d_record, sizeof(pcl_brush_input)));
     PCL_HIP_TRY(hipMalloc((void**)&c->d_agree, 8 * sizeof(unsigned long long)));
     PCL_HIP_TRY(hipHostMalloc((void**)&c->h_agree, 8 * sizeof(unsigned long long), hipHostMallocDefault));
@@ -368,25 +408,68 @@ int brush_event(const Span& s, const pcl_brush_input* in, int root, bool down)
     return PCL_OK;
 }
 
+// Before a step whose record will be all-reduced beside the next step: the handle writes that record
+// into the slot that is free, once the all-reduce that last read the slot (two steps ago) has finished.
+int arm_diagnostics_slot(pcl_compute* h, Comm* c)
+{
+    const int k = c->next_slot;
+    c->next_slot ^= 1;
+    if (int rc = pcl_internal::make_current(h)) return rc;
+    PCL_HIP_TRY(hipStreamWaitEvent(pcl_internal::stream_of(h), c->ev_done[k], 0));   // never recorded: no wait
+    pcl_internal::set_diag_target(h, c->d_slot + k);
+    c->armed_slot = k;
+    return PCL_OK;
+}
+
 // Sum {count, kinetic energy} (f64) and max {max xyz, -min xyz} (f32) of every handle's record
-// into its d_global: one group call, two all-reduces per handle.
-int allreduce_diagnostics(const Span& s)
+// into its d_global: one group call, two all-reduces per handle.  `beside` (the per-step all-reduce):
+// on the side stream, from the slot armed for the step, while the handle's stream goes on with the
+// next step; otherwise on the handle's stream, after whatever the side stream still has to write
+// into d_global.
+int allreduce_diagnostics(const Span& s, bool beside)
 {
     std::vector<const void*> local(s.n, nullptr);
     for (int i = 0; i < s.n; ++i)
         if (int rc = pcl_internal::diagnostics_on_device(s.h[i], &local[i])) return rc;
-    GroupScope group;   // always: two all-reduces per handle travel as one call
-    if (int rc = group.begin(true)) return rc;
+    std::vector<int> slot(s.n, -1);
     for (int i = 0; i < s.n; ++i) {
         pcl_compute* h = s.h[i];
         Comm* c = comm_of(h);
         if (int rc = pcl_internal::make_current(h)) return rc;
-        const char* in = static_cast<const char*>(local[i]);
-        char* out = reinterpret_cast<char*>(c->d_global);
-        PCL_NCCL_TRY(g_rccl.AllReduce(in, out, 2, ncclDouble, ncclSum, c->comm, pcl_internal::stream_of(h)));
-        PCL_NCCL_TRY(g_rccl.AllReduce(in + 16, out + 16, 6, ncclFloat, ncclMax, c->comm, pcl_internal::stream_of(h)));
+        hipStream_t own = pcl_internal::stream_of(h);
+        if (!beside) {
+            if (int rc = order_after_side(h, c)) return rc;
+            continue;
+        }
+        const int k = slot[i] = c->armed_slot;
+        PCL_REQUIRE(k >= 0 && local[i] == c->d_slot + k, "the step's record is not in the slot armed for it");
+        PCL_HIP_TRY(hipEventRecord(c->ev_ready[k], own));
+        PCL_HIP_TRY(hipStreamWaitEvent(c->side, c->ev_ready[k], 0));
     }
-    return group.end();
+    {
+        GroupScope group;   // always: two all-reduces per handle travel as one call
+        if (int rc = group.begin(true)) return rc;
+        for (int i = 0; i < s.n; ++i) {
+            pcl_compute* h = s.h[i];
+            Comm* c = comm_of(h);
+            if (int rc = pcl_internal::make_current(h)) return rc;
+            const char* in = beside ? reinterpret_cast<const char*>(c->d_slot + slot[i]) : static_cast<const char*>(local[i]);
+            char* out = reinterpret_cast<char*>(c->d_global);
+            hipStream_t stream = beside ? c->side : pcl_internal::stream_of(h);
+            PCL_NCCL_TRY(g_rccl.AllReduce(in, out, 2, ncclDouble, ncclSum, c->comm, stream));
+            PCL_NCCL_TRY(g_rccl.AllReduce(in + 16, out + 16, 6, ncclFloat, ncclMax, c->comm, stream));
+        }
+        if (int rc = group.end()) return rc;
+    }
+    if (beside)
+        for (int i = 0; i < s.n; ++i) {
+            pcl_compute* h = s.h[i];
+            Comm* c = comm_of(h);
+            if (int rc = pcl_internal::make_current(h)) return rc;
+            PCL_HIP_TRY(hipEventRecord(c->ev_done[slot[i]], c->side));
+            c->pending_slot = slot[i];
+        }
+    return PCL_OK;
 }
 
 // What the ranks agree on before they step together: the largest local particle count (every range
@@ -487,6 +570,9 @@ int step(const Span& s)
     }
     if (!agreement_current(s, pairs, diag))
         if (int rc = agree(s, pairs, diag)) return rc;
+    if (diag)
+        for (int i = 0; i < s.n; ++i)
+            if (int rc = arm_diagnostics_slot(s.h[i], comm_of(s.h[i]))) return rc;
     if (!pairs) {
         for (int i = 0; i < s.n; ++i)
             if (int rc = pcl_step(s.h[i])) return rc;
@@ -529,7 +615,7 @@ int step(const Span& s)
                 if (int rc = pcl_step_pairs_gathered(s.h[i], comm_of(s.h[i])->d_pair_recv, cap * world)) return rc;
         }
     }
-    if (diag) return allreduce_diagnostics(s);
+    if (diag) return allreduce_diagnostics(s, true);
     return PCL_OK;
 }
 
@@ -537,7 +623,7 @@ int diagnostics_read(const Span& s, pcl_diagnostics* out)
 {
     if (int rc = check_span(s)) return rc;
     PCL_REQUIRE(out != nullptr, "out is null");
-    if (int rc = allreduce_diagnostics(s)) return rc;
+    if (int rc = allreduce_diagnostics(s, false)) return rc;
     pcl_compute* h = s.h[0];
     if (int rc = pcl_internal::make_current(h)) return rc;
     PCL_HIP_TRY(hipMemcpyAsync(out, comm_of(h)->d_global, sizeof(pcl_diagnostics), hipMemcpyDeviceToHost,
@@ -601,6 +687,7 @@ int pcl_comm_detach(pcl_compute* h)
     PCL_REQUIRE(h != nullptr, "null handle");
     if (!comm_of(h)) return PCL_OK;
     if (int rc = pcl_synchronize(h)) return rc;
+    pcl_internal::set_diag_target(h, nullptr);   // the handle's own record again: the slots go with the communicator
     release_comm(comm_of(h));
     pcl_internal::set_comm(h, nullptr, nullptr);
     return PCL_OK;
@@ -660,6 +747,9 @@ int pcl_comm_diagnostics_read(pcl_compute* h, pcl_diagnostics* out) { return dia
 int pcl_comm_diagnostics_device(pcl_compute* h, const void** dev_record)
 {
     PCL_REQUIRE(h != nullptr && dev_record != nullptr && comm_of(h) != nullptr, "pcl_comm_diagnostics_device: no communicator");
+    // what the caller enqueues on the handle's stream from here on sees the latest step's all-reduce finished
+    if (int rc = pcl_internal::make_current(h)) return rc;
+    if (int rc = order_after_side(h, comm_of(h))) return rc;
     *dev_record = comm_of(h)->d_global;
     return PCL_OK;
 }

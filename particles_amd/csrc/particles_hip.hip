@@ -209,7 +209,8 @@ struct pcl_compute {
 
     pcl::DiagPartial* d_partials = nullptr;
     size_t partials_capacity = 0;
-    pcl::DiagOut* d_diag = nullptr;
+    pcl::DiagOut* d_diag = nullptr;       // where reductions write the record: d_diag_own, or memory of the multi-GPU layer
+    pcl::DiagOut* d_diag_own = nullptr;
 
     uint32_t grid_cap = 0;  // 0: default
     uint32_t variant = 0;
@@ -221,6 +222,7 @@ struct pcl_compute {
     // state of the multi-GPU layer (particles_comm.hip), released in pcl_destroy
     void* comm = nullptr;
     void (*comm_release)(void*) = nullptr;
+    int (*comm_sync)(void*) = nullptr;
 
     // per-step launch timing (pcl_step_timing_*): one event pair per step
     std::vector<hipEvent_t> timing_events;
@@ -242,6 +244,8 @@ int bind(const pcl_compute* h)
 // device error word since the last report (the word is cleared).
 int sync_stream(pcl_compute* h)
 {
+    if (h->comm && h->comm_sync)
+        if (int rc = h->comm_sync(h->comm)) return rc;
     if (!h->d_error) {
         PCL_HIP_TRY(hipStreamSynchronize(h->stream));
         return PCL_OK;
@@ -1545,7 +1549,12 @@ size_t cells_of(const pcl_compute* h) { return h->n_cells; }
 bool pair_term_active(const pcl_compute* h) { return !pair_term_inert(h->params); }
 bool step_diagnostics_enabled(const pcl_compute* h) { return h->step_diag; }
 uint64_t particles_epoch(const pcl_compute* h) { return h->particles_epoch; }
-void set_comm(pcl_compute* h, void* comm, void (*release)(void*)) { h->comm = comm; h->comm_release = release; }
+void set_comm(pcl_compute* h, void* comm, void (*release)(void*), int (*sync)(void*))
+{
+    h->comm = comm;
+    h->comm_release = release;
+    h->comm_sync = sync;
+}
 void* comm_of(const pcl_compute* h) { return h->comm; }
 
 int field_for_write(pcl_compute* h, size_t n_cells, void** dev_field)
@@ -1559,6 +1568,14 @@ int field_for_write(pcl_compute* h, size_t n_cells, void** dev_field)
     h->field_checked = false;
     *dev_field = h->field;
     return PCL_OK;
+}
+
+void set_diag_target(pcl_compute* h, void* dev_record)
+{
+    pcl::DiagOut* target = dev_record ? static_cast<pcl::DiagOut*>(dev_record) : h->d_diag_own;
+    if (target == h->d_diag) return;
+    h->d_diag = target;
+    h->diag_current = false;   // the record of the current state, if any, is in the other place
 }
 
 int diagnostics_on_device(pcl_compute* h, const void** dev_record)
@@ -1601,6 +1618,7 @@ int pcl_destroy(pcl_compute* h)
     (void)hipSetDevice(h->device);
     if (h->comm && h->comm_release) h->comm_release(h->comm);   // while the stream still exists
     h->comm = nullptr;
+    h->comm_sync = nullptr;
     (void)hipStreamSynchronize(h->stream);   // a null handle names the device's null stream
     if (h->own_stream && h->own_stream != h->stream) (void)hipStreamSynchronize(h->own_stream);
     free_particles(h);
@@ -1608,7 +1626,7 @@ int pcl_destroy(pcl_compute* h)
     if (h->field3) (void)hipFree(h->field3);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_partials) (void)hipFree(h->d_partials);
-    if (h->d_diag) (void)hipFree(h->d_diag);
+    if (h->d_diag_own) (void)hipFree(h->d_diag_own);
     if (h->d_hist) (void)hipFree(h->d_hist);
     if (h->d_runs) (void)hipFree(h->d_runs);
     if (h->d_cellsort) (void)hipFree(h->d_cellsort);
@@ -1681,7 +1699,8 @@ int pcl_create(const pcl_particle* particles, size_t n, const float (*force_grid
     PCL_CREATE_TRY(hipEventCreate(&h->ev_start));
     PCL_CREATE_TRY(hipEventCreate(&h->ev_stop));
     PCL_CREATE_TRY(hipMalloc((void**)&h->d_params, sizeof(pcl_sim_params)));
-    PCL_CREATE_TRY(hipMalloc((void**)&h->d_diag, sizeof(pcl::DiagOut)));
+    PCL_CREATE_TRY(hipMalloc((void**)&h->d_diag_own, sizeof(pcl::DiagOut)));
+    h->d_diag = h->d_diag_own;
     PCL_CREATE_TRY(hipMalloc((void**)&h->d_field_flag, sizeof(uint32_t)));
     PCL_CREATE_TRY(hipMalloc((void**)&h->d_error, sizeof(uint32_t)));
     PCL_CREATE_TRY(hipMemset(h->d_error, 0, sizeof(uint32_t)));

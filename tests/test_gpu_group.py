@@ -234,3 +234,48 @@ def test_comm_attach_one_rank_runs_every_collective(oracle):
         check_diag(diag_of(bytes(d)), pdiag)
         _lib.check(lib.pcl_comm_detach(h))
         assert lib.pcl_comm_world(h) == 0
+
+
+@pytest.mark.gpu
+def test_the_all_reduce_of_a_step_runs_beside_the_next_step_and_holds_that_steps_record(oracle):
+    """With step diagnostics on, pcl_comm_step starts the all-reduce of the step's record on a stream of
+    the communicator's own and the handle's stream goes on.  What pcl_comm_diagnostics_device points at
+    must, for work enqueued on the handle's stream after that call, be the record of the step just
+    issued: here the library's own stream-ordered copy (pcl_patch_force_grid_device) carries the 48 bytes
+    into three field cells with no host synchronisation in between, after every one of 26 steps (one
+    refresh of the particle order among them), and the oracle says what they must be."""
+    lib = _lib.load()
+    n, dims = 300_000, (64, 64, 1)
+    cells = dims[0] * dims[1]
+    rng = np.random.default_rng(31)
+    g = np.ones((cells, 4), dtype=np.float32)
+    g[:, :3] = rng.uniform(-1, 1, size=(cells, 3)).astype(np.float32)
+    sp = pa.SimParams()
+    sp.delta_t = np.float32(1.0 / 60.0)
+    sp.force_grid_dimensions = dims
+    sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+    state = oracle.synth_particles(n, 77, 0, 20.0, 10.0)
+    uid = (C.c_char * _lib.UNIQUE_ID_BYTES)()
+    _lib.check(lib.pcl_comm_unique_id(uid))
+    with pa.Compute.new(state, g) as c:
+        h = c._h
+        _lib.check(lib.pcl_comm_attach(h, uid, 0, 1))
+        c.update_sim_params(sp)
+        c.set_reorder_interval(12)
+        c.enable_step_diagnostics(True)
+        keep = np.ascontiguousarray(g[cells - 3:])
+        for step in range(26):
+            _lib.check(lib.pcl_comm_step(h))
+            rec = C.c_void_p()
+            _lib.check(lib.pcl_comm_diagnostics_device(h, C.byref(rec)))
+            _lib.check(lib.pcl_patch_force_grid_device(h, cells - 3, rec, 3))
+            got = diag_of(c.read_force_grid(cells - 3, 3).tobytes())
+            _lib.check(lib.pcl_patch_force_grid(h, cells - 3, keep.ctypes.data_as(C.c_void_p), 3))
+            state = oracle.step(sp, state, g, mode=oracle.MODE_SKIP_INERT)
+            want = oracle.diagnostics(sp, state)
+            assert got["count"] == want["count"] == n, step
+            assert np.array_equal(got["pos_max"], want["pos_max"]) and np.array_equal(got["pos_min"], want["pos_min"]), step
+            assert abs(got["kinetic_energy"] - want["kinetic_energy"]) <= 1e-11 * want["kinetic_energy"], step
+        assert c.reorder_count >= 2
+        assert_particles_bit_equal(c.read_particles(), state, "after 26 steps with the all-reduce beside them")
+        _lib.check(lib.pcl_comm_detach(h))
