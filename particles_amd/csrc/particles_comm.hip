@@ -137,10 +137,18 @@ int need_rccl()
     } while (0)
 
 // ---- per-handle communicator state ---------------------------------------------
+constexpr int kRecordRing = 8;
+
 struct Comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     void* d_record = nullptr;          // 64-byte cursor record as broadcast
+    // The root's records wait in pinned memory for their copy to the device, so that a brush event
+    // never makes the host wait for the stream (the caller's record is only valid during the call):
+    // a ring of kRecordRing, a slot taken again once the copy made from it eight events ago has run.
+    pcl_brush_input* h_records = nullptr;
+    hipEvent_t ev_record_copied[8] = {};
+    int record_next = 0;
     char* d_stage = nullptr;           // indexed patches: cells then indices
     size_t stage_bytes = 0;
     float* d_pair_send = nullptr;      // this range's 16-byte (x, y, z, type) records, padded
@@ -182,6 +190,9 @@ void release_comm(void* p)
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->d_slot) (void)hipFree(c->d_slot);
     if (c->d_record) (void)hipFree(c->d_record);
+    if (c->h_records) (void)hipHostFree(c->h_records);
+    for (hipEvent_t e : c->ev_record_copied)
+        if (e) (void)hipEventDestroy(e);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_pair_send) (void)hipFree(c->d_pair_send);
     if (c->d_pair_recv) (void)hipFree(c->d_pair_recv);
@@ -223,6 +234,8 @@ int adopt(pcl_compute* h, ncclComm_t comm, int rank, int world)
     }
     PCL_HIP_TRY(hipMalloc((void**)&c->d_slot, 2 * sizeof(pcl_diagnostics)));
     PCL_HIP_TRY(hipMalloc(&c->d_record, sizeof(pcl_brush_input)));
+    PCL_HIP_TRY(hipHostMalloc((void**)&c->h_records, kRecordRing * sizeof(pcl_brush_input), hipHostMallocDefault));
+    for (int k = 0; k < kRecordRing; ++k) PCL_HIP_TRY(hipEventCreateWithFlags(&c->ev_record_copied[k], hipEventDisableTiming));
     PCL_HIP_TRY(hipMalloc((void**)&c->d_agree, 8 * sizeof(unsigned long long)));
     PCL_HIP_TRY(hipHostMalloc((void**)&c->h_agree, 8 * sizeof(unsigned long long), hipHostMallocDefault));
     PCL_HIP_TRY(hipMalloc((void**)&c->d_global, sizeof(pcl_diagnostics)));
@@ -384,9 +397,14 @@ int brush_event(const Span& s, const pcl_brush_input* in, int root, bool down)
         PCL_REQUIRE(in->mode >= PCL_EDIT_CENTERED && in->mode <= PCL_EDIT_ROTATE, "unknown edit mode");
         PCL_REQUIRE(in->falloff >= PCL_FALLOFF_ABRUPT && in->falloff <= PCL_FALLOFF_INVERSE_DISTANCE, "unknown falloff");
         if (int rc = pcl_internal::make_current(r)) return rc;
-        PCL_HIP_TRY(hipMemcpyAsync(comm_of(r)->d_record, in, sizeof(pcl_brush_input), hipMemcpyHostToDevice,
+        Comm* c = comm_of(r);
+        const int k = c->record_next;
+        c->record_next = (k + 1) % kRecordRing;
+        PCL_HIP_TRY(hipEventSynchronize(c->ev_record_copied[k]));   // eight events old (never recorded: returns at once)
+        c->h_records[k] = *in;
+        PCL_HIP_TRY(hipMemcpyAsync(c->d_record, &c->h_records[k], sizeof(pcl_brush_input), hipMemcpyHostToDevice,
                                    pcl_internal::stream_of(r)));
-        PCL_HIP_TRY(hipStreamSynchronize(pcl_internal::stream_of(r)));
+        PCL_HIP_TRY(hipEventRecord(c->ev_record_copied[k], pcl_internal::stream_of(r)));
     }
     {
         GroupScope group;

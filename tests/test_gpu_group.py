@@ -279,3 +279,45 @@ def test_the_all_reduce_of_a_step_runs_beside_the_next_step_and_holds_that_steps
         assert c.reorder_count >= 2
         assert_particles_bit_equal(c.read_particles(), state, "after 26 steps with the all-reduce beside them")
         _lib.check(lib.pcl_comm_detach(h))
+
+
+@pytest.mark.gpu
+def test_a_long_stroke_through_the_communicator_equals_the_oracles():
+    """Twenty cursor records in a row through pcl_comm_brush_mouse_moved with a step after each (the root's
+    records queue in a ring of pinned slots, never making the host wait for the stream; twenty wrap the ring
+    twice), mirrored call by call on the oracle: same field bytes, same particles."""
+    lib = _lib.load()
+    n, dims = 20_000, (32, 32, 4)
+    cells = dims[0] * dims[1] * dims[2]
+    rng = np.random.default_rng(5)
+    g = np.ones((cells, 4), dtype=np.float32)
+    g[:, :3] = rng.uniform(-1, 1, size=(cells, 3)).astype(np.float32)
+    sp = pa.SimParams()
+    sp.delta_t = np.float32(1.0 / 60.0)
+    sp.force_grid_dimensions = dims
+    p = pa.random_particles(n, np.random.default_rng(6), pos_max=20.0)
+    model = OracleCompute(p, g)
+    model.update_sim_params(sp)
+    mode = pa.EditMode(mode="shift", relative=True, falloff="linear", falloff_dist=3.0, strength=0.7)
+    uid = (C.c_char * _lib.UNIQUE_ID_BYTES)()
+    _lib.check(lib.pcl_comm_unique_id(uid))
+    with pa.Compute.new(p, g) as c:
+        h = c._h
+        _lib.check(lib.pcl_comm_attach(h, uid, 0, 1))
+        c.update_sim_params(sp)
+        rec = np.ascontiguousarray(mode.record((0.0, 0.0, 0.0)))
+        _lib.check(lib.pcl_comm_brush_mouse_down(h, rec.ctypes.data_as(C.c_void_p), 0))
+        model.brush_mouse_down(rec)
+        for k in range(20):
+            rec = np.ascontiguousarray(mode.record((0.2 * k, 0.1 * k, -0.05 * k)))
+            _lib.check(lib.pcl_comm_brush_mouse_moved(h, rec.ctypes.data_as(C.c_void_p), 0))
+            rec.view(np.uint8)[:] = 0                   # the record is the caller's again as soon as the call returns
+            model.brush_mouse_moved(np.ascontiguousarray(mode.record((0.2 * k, 0.1 * k, -0.05 * k))))
+            _lib.check(lib.pcl_comm_step(h))
+            model.compute()
+        c.brush_mouse_up()
+        model.brush_mouse_up()
+        assert c.read_force_grid().tobytes() == model.read_force_grid().tobytes()
+        assert not np.array_equal(model.read_force_grid(), g)
+        assert_particles_bit_equal(c.read_particles(), model.read_particles(), "a stroke of 20 records through the communicator")
+        _lib.check(lib.pcl_comm_detach(h))
