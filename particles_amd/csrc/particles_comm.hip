@@ -151,6 +151,12 @@ struct Comm {
     int record_next = 0;
     char* d_stage = nullptr;           // indexed patches: cells then indices
     size_t stage_bytes = 0;
+    // The root's cells and indices wait in pinned memory for their copy to the device (the caller's arrays
+    // are only valid during the call): two buffers taken in turn, each again once its last copy has run.
+    char* h_stage[2] = {nullptr, nullptr};
+    size_t h_stage_bytes[2] = {0, 0};
+    hipEvent_t ev_stage_copied[2] = {nullptr, nullptr};
+    int stage_next = 0;
     float* d_pair_send = nullptr;      // this range's 16-byte (x, y, z, type) records, padded
     float* d_pair_recv = nullptr;      // all ranges' records
     size_t pair_cap = 0;               // records per range in those buffers
@@ -194,6 +200,10 @@ void release_comm(void* p)
     for (hipEvent_t e : c->ev_record_copied)
         if (e) (void)hipEventDestroy(e);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    for (int k = 0; k < 2; ++k) {
+        if (c->h_stage[k]) (void)hipHostFree(c->h_stage[k]);
+        if (c->ev_stage_copied[k]) (void)hipEventDestroy(c->ev_stage_copied[k]);
+    }
     if (c->d_pair_send) (void)hipFree(c->d_pair_send);
     if (c->d_pair_recv) (void)hipFree(c->d_pair_recv);
     if (c->d_agree) (void)hipFree(c->d_agree);
@@ -236,6 +246,7 @@ int adopt(pcl_compute* h, ncclComm_t comm, int rank, int world)
     PCL_HIP_TRY(hipMalloc(&c->d_record, sizeof(pcl_brush_input)));
     PCL_HIP_TRY(hipHostMalloc((void**)&c->h_records, kRecordRing * sizeof(pcl_brush_input), hipHostMallocDefault));
     for (int k = 0; k < kRecordRing; ++k) PCL_HIP_TRY(hipEventCreateWithFlags(&c->ev_record_copied[k], hipEventDisableTiming));
+    for (int k = 0; k < 2; ++k) PCL_HIP_TRY(hipEventCreateWithFlags(&c->ev_stage_copied[k], hipEventDisableTiming));
     PCL_HIP_TRY(hipMalloc((void**)&c->d_agree, 8 * sizeof(unsigned long long)));
     PCL_HIP_TRY(hipHostMalloc((void**)&c->h_agree, 8 * sizeof(unsigned long long), hipHostMallocDefault));
     PCL_HIP_TRY(hipMalloc((void**)&c->d_global, sizeof(pcl_diagnostics)));
@@ -366,9 +377,20 @@ int patch_force_grid_indexed(const Span& s, const uint32_t* idx, const float (*c
                 return fail(PCL_ERR_OUT_OF_RANGE, "patch_force_grid_indexed: cell index outside the field");
         Comm* c = comm_of(r);
         if (int rc = pcl_internal::make_current(r)) return rc;
-        PCL_HIP_TRY(hipMemcpyAsync(c->d_stage, cells, count * 16, hipMemcpyHostToDevice, pcl_internal::stream_of(r)));
-        PCL_HIP_TRY(hipMemcpyAsync(c->d_stage + count * 16, idx, count * 4, hipMemcpyHostToDevice, pcl_internal::stream_of(r)));
-        PCL_HIP_TRY(hipStreamSynchronize(pcl_internal::stream_of(r)));   // the caller's buffers are only valid during the call
+        const int k = c->stage_next;
+        c->stage_next ^= 1;
+        PCL_HIP_TRY(hipEventSynchronize(c->ev_stage_copied[k]));   // two patches old (never recorded: returns at once)
+        if (c->h_stage_bytes[k] < bytes) {
+            if (c->h_stage[k]) PCL_HIP_TRY(hipHostFree(c->h_stage[k]));
+            c->h_stage[k] = nullptr;
+            c->h_stage_bytes[k] = 0;
+            PCL_HIP_TRY(hipHostMalloc((void**)&c->h_stage[k], bytes, hipHostMallocDefault));
+            c->h_stage_bytes[k] = bytes;
+        }
+        std::memcpy(c->h_stage[k], cells, count * 16);
+        std::memcpy(c->h_stage[k] + count * 16, idx, count * 4);
+        PCL_HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage[k], bytes, hipMemcpyHostToDevice, pcl_internal::stream_of(r)));
+        PCL_HIP_TRY(hipEventRecord(c->ev_stage_copied[k], pcl_internal::stream_of(r)));
     }
     {
         GroupScope group;

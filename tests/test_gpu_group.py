@@ -321,3 +321,42 @@ def test_a_long_stroke_through_the_communicator_equals_the_oracles():
         assert not np.array_equal(model.read_force_grid(), g)
         assert_particles_bit_equal(c.read_particles(), model.read_particles(), "a stroke of 20 records through the communicator")
         _lib.check(lib.pcl_comm_detach(h))
+
+
+@pytest.mark.gpu
+def test_indexed_patches_in_a_row_through_the_communicator_equal_the_oracles():
+    """Seven indexed patches of different sizes through pcl_comm_patch_force_grid_indexed with steps between
+    them; the caller's arrays are overwritten as soon as each call returns (the root's copy of them waits in
+    pinned memory for the stream, the host does not wait)."""
+    lib = _lib.load()
+    n, dims = 50_000, (48, 48, 1)
+    cells = dims[0] * dims[1]
+    rng = np.random.default_rng(15)
+    g = np.ones((cells, 4), dtype=np.float32)
+    g[:, :3] = rng.uniform(-1, 1, size=(cells, 3)).astype(np.float32)
+    sp = pa.SimParams()
+    sp.delta_t = np.float32(1.0 / 60.0)
+    sp.force_grid_dimensions = dims
+    p = pa.random_particles(n, np.random.default_rng(16), pos_max=20.0)
+    model = OracleCompute(p, g)
+    model.update_sim_params(sp)
+    uid = (C.c_char * _lib.UNIQUE_ID_BYTES)()
+    _lib.check(lib.pcl_comm_unique_id(uid))
+    with pa.Compute.new(p, g) as c:
+        h = c._h
+        _lib.check(lib.pcl_comm_attach(h, uid, 0, 1))
+        c.update_sim_params(sp)
+        for count in (5, 900, 1, 2304, 64, 1500, 3):
+            idx = rng.choice(cells, size=count, replace=False).astype(np.uint32)
+            val = np.ones((count, 4), dtype=np.float32)
+            val[:, :3] = rng.uniform(-3, 3, size=(count, 3)).astype(np.float32)
+            model.patch_force_grid_indexed(idx.copy(), val.copy())
+            _lib.check(lib.pcl_comm_patch_force_grid_indexed(h, idx.ctypes.data_as(C.c_void_p), val.ctypes.data_as(C.c_void_p), count, 0))
+            idx[:] = 0
+            val[:] = np.float32(777.0)
+            for _ in range(2):
+                _lib.check(lib.pcl_comm_step(h))
+                model.compute()
+        assert c.read_force_grid().tobytes() == model.read_force_grid().tobytes()
+        assert_particles_bit_equal(c.read_particles(), model.read_particles(), "indexed patches through the communicator")
+        _lib.check(lib.pcl_comm_detach(h))
