@@ -445,8 +445,11 @@ enum {
     PCL_STEP_STREAM_FUSED   = 7  /* step_stream_fused_kernel: several updates in one launch      */
 };
 
-/* Per-launch timing: between begin and read every pcl_step is bracketed by a
- * HIP event pair on the handle's stream (no synchronisation until the read).
+/* Per-launch timing: between begin and read every pcl_step is timed by a HIP
+ * event pair on the handle's stream (no synchronisation until the read): a step
+ * that is one plain kernel launch hands the pair to that launch, which stamps
+ * it with the kernel's own begin and end and puts nothing else on the stream;
+ * every other kind of step lies between two event records.
  * read waits for the last step, fills elapsed_ms[i] / kinds[i] (PCL_STEP_*) for
  * the recorded steps and stops the recording. */
 int pcl_step_timing_begin(pcl_compute* h, size_t max_steps);
@@ -506,6 +509,8 @@ int pcl_pair_sweep_info(const pcl_compute* h, uint32_t* shared_sweep, uint32_t* 
  *   0x800000 / 0x80000000  cell-binned pair term: always the sweep with one particle per lane / always the sweep with
  *            the candidates shared by a wave (automatic: by the particles per occupied cut-off cell)
  *   0x200    particles in caller order are sorted once instead of twice before their first step
+ *   0x800    step timing (pcl_step_timing_begin): an event record on either side of EVERY step instead of
+ *            handing the two events of a one-kernel step to that launch
  *   0x40000  tests only: the next refresh of the particle order scatters with other keys than its
  *            histogram counted, which the kernel reports as PCL_ERR_DEVICE (the state is then unusable) */
 int pcl_set_tuning(pcl_compute* h, uint32_t grid_blocks, uint32_t variant);

@@ -16,6 +16,7 @@
 
 #include "particles_hip.h"
 #include "handle_access.hpp"
+#include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: a launch that stamps two events with its own begin and end
 
 #include <algorithm>
 #include <atomic>
@@ -229,6 +230,11 @@ struct pcl_compute {
     std::vector<int> timing_kinds;
     size_t timing_used = 0;
     bool timing_on = false;
+    // A timed step starts with its start event NOT yet on the stream (kTimingDeferred): a step that turns out to
+    // be one plain kernel hands both events to that launch (hipExtLaunchKernelGGL: the kernel's own begin and end
+    // stamps, no packets of their own on the stream); every other kind records the start event before its first
+    // launch (timing_start_now) and do_step records the stop event behind its last.
+    int timing_state = 0;
 };
 
 namespace {
@@ -332,6 +338,8 @@ bool use_field3(const pcl_compute* h)
 }
 
 // What a streaming launch needs beside the field itself: the packed copy (*out; null when not used)
+int timing_start_now(pcl_compute* h);   // below: a timed step's start event goes on the stream before its first launch
+
 // and the window flag, both brought up to date with the field in one pass when either is stale.
 int current_field3(pcl_compute* h, const float** out)
 {
@@ -347,6 +355,7 @@ int current_field3(pcl_compute* h, const float** out)
         h->field3_capacity = h->field_capacity;
     }
     if (!h->field_checked || (packed && !h->field3_valid)) {
+        if (int rc = timing_start_now(h)) return rc;
         PCL_HIP_TRY(hipMemsetAsync(h->d_field_flag, 0, sizeof(uint32_t), h->stream));
         const size_t blocks = (h->n_cells + pcl::kBlockThreads - 1) / pcl::kBlockThreads;
         hipLaunchKernelGGL(pcl::prepare_field_kernel, dim3((uint32_t)std::min<size_t>(blocks, 4096)), dim3(pcl::kBlockThreads), 0,
@@ -571,6 +580,17 @@ int granted_blocks_per_cu(const void* kernel, int device, int block, size_t lds_
     return PCL_OK;
 }
 
+enum { kTimingOff = 0, kTimingDeferred = 1, kTimingStarted = 2, kTimingAttached = 3 };
+
+// The start event of a timed step goes on the stream now, unless it is there already.
+int timing_start_now(pcl_compute* h)
+{
+    if (h->timing_state != kTimingDeferred) return PCL_OK;
+    PCL_HIP_TRY(hipEventRecord(h->timing_events[2 * h->timing_used], h->stream));
+    h->timing_state = kTimingStarted;
+    return PCL_OK;
+}
+
 // Which tiles the blocks of the plain streaming step take (StreamArgs::xcd_chunk; 0: block b takes tile b).
 // Blocks are dealt round-robin over the 8 XCDs, so in tile order every XCD's L2 fetches every field tile that
 // has particles.  That is noise while a field tile holds many blocks' worth of particles, and a second stream
@@ -626,8 +646,17 @@ int launch_plain_shaped(pcl_compute* h, const pcl::StreamArgs& a, const pcl::Ste
         if (!reported.exchange(true)) std::fprintf(stderr, "particles_hip: %s\n", g_last_error.c_str());
         pad = 0;
     }
-    hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, false, false, BLOCK>), dim3((uint32_t)blocks), dim3(BLOCK),
-                       pad, h->stream, args, U, T);
+    if (!DIAG && h->timing_state == kTimingDeferred) {
+        // the whole step is this one launch: its own begin and end are the step's time
+        hipExtLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, false, false, BLOCK>), dim3((uint32_t)blocks), dim3(BLOCK),
+                              pad, h->stream, h->timing_events[2 * h->timing_used], h->timing_events[2 * h->timing_used + 1], 0,
+                              args, U, T);
+        h->timing_state = kTimingAttached;
+    } else {
+        if (int rc = timing_start_now(h)) return rc;
+        hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, false, false, BLOCK>), dim3((uint32_t)blocks), dim3(BLOCK),
+                           pad, h->stream, args, U, T);
+    }
     PCL_HIP_TRY(hipGetLastError());
     grid = (uint32_t)blocks;   // what the fold of the partials has to cover
     return PCL_OK;
@@ -688,6 +717,7 @@ int launch_stream(pcl_compute* h, const pcl::StreamArgs& a, const pcl::StepUnifo
             }
         }
     }
+    if (int rc = timing_start_now(h)) return rc;
     if (lds) {
         const size_t bytes = (size_t)a.lds_cells * sizeof(pcl::f32x4);
         hipLaunchKernelGGL((pcl::step_stream_kernel<DIAG, NT, true, false>), dim3(grid),
@@ -1128,6 +1158,8 @@ int do_step_impl(pcl_compute* h, int* kind)
     uint32_t advanced = 1;   // steps this launch performs
 
     bool flipped = false;   // the launch already flipped the buffers
+    if (use_pairs)
+        if (int rc = timing_start_now(h)) return rc;
     if (!use_pairs) {
         poll_refresh_pacing(h);
         const int interval = effective_reorder_interval(h);
@@ -1139,6 +1171,7 @@ int do_step_impl(pcl_compute* h, int* kind)
         // which the scatter kernel must detect and report through the error word
         if (sort_now && h->hist_valid && (h->variant & 0x40000u)) T.lookahead += 1.0f;
         if (sort_now) {
+            if (int rc = timing_start_now(h)) return rc;
             // Particles in caller order (fresh upload) are sorted twice: first by the tile they were in half an
             // interval AGO, then, below, like every refresh, by the tile they will be in half an interval from
             // now.  A refresh appends each source tile's particles to their new tile in source order, so from
@@ -1179,6 +1212,7 @@ int do_step_impl(pcl_compute* h, int* kind)
                                (h->variant & 8u) == 0;
             grid = stream_grid(h);
             if (count) {
+                if (int rc = timing_start_now(h)) return rc;
                 if (int rc = reserve_reorder(h)) return rc;
                 // One tile per block here too: blocks dispatched together then work on
                 // neighbouring tiles, which is what keeps the field fetches cache-resident
@@ -1230,6 +1264,7 @@ int do_step_impl(pcl_compute* h, int* kind)
                 advanced = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(room, 1u), kMaxFusedSteps);
             }
             if (advanced > 1) {
+                if (int rc = timing_start_now(h)) return rc;
                 const size_t tiles = stream_tiles(h->n);   // the fused kernel takes exactly one tile per block
                 PCL_REQUIRE(tiles <= 0x7FFFFFFFu, "too many particles for one launch");
                 grid = (uint32_t)tiles;
@@ -1398,11 +1433,18 @@ int do_step(pcl_compute* h)
     const bool timed = h && h->timing_on && h->timing_used < h->timing_kinds.size();
     if (timed) {
         if (int rc = bind(h)) return rc;
-        PCL_HIP_TRY(hipEventRecord(h->timing_events[2 * h->timing_used], h->stream));
+        h->timing_state = kTimingDeferred;
+        // tuning bit 0x800: an event record on either side of every step, whatever its kind
+        if (h->variant & 0x800u)
+            if (int rc = timing_start_now(h)) return rc;
     }
     const int rc = do_step_impl(h, &kind);
     if (timed) {
-        PCL_HIP_TRY(hipEventRecord(h->timing_events[2 * h->timing_used + 1], h->stream));
+        const int state = h->timing_state;
+        h->timing_state = kTimingOff;
+        if (state == kTimingDeferred)   // nothing was launched (no particles, or an error on the way)
+            PCL_HIP_TRY(hipEventRecord(h->timing_events[2 * h->timing_used], h->stream));
+        if (state != kTimingAttached) PCL_HIP_TRY(hipEventRecord(h->timing_events[2 * h->timing_used + 1], h->stream));
         h->timing_kinds[h->timing_used] = rc == PCL_OK ? kind : PCL_STEP_NONE;
         h->timing_used += 1;
     }
