@@ -325,8 +325,18 @@ void walk_comm(pcl_compute* h, const std::vector<float>& field, size_t n_cells, 
     pcl_brush_input in;
     pcl_brush_input_default(&in);
     OK(pcl_comm_brush_mouse_down(h, &in, 0));
-    OK(pcl_comm_brush_mouse_moved(h, &in, 0));
+    for (int e = 0; e < 20; ++e) {           // more events than the ring of pinned records holds
+        in.cursor_pos[0] = 0.1f * (float)e;
+        OK(pcl_comm_brush_mouse_moved(h, &in, 0));
+        OK(pcl_comm_step(h));
+    }
     OK(pcl_brush_mouse_up(h));
+    for (size_t count : {(size_t)3, (size_t)700, (size_t)1, (size_t)2000, (size_t)40}) {   // pinned staging grows and is reused
+        std::vector<uint32_t> list(count);
+        for (size_t k = 0; k < count; ++k) list[k] = (uint32_t)((k * 7919u) % n_cells);
+        OK(pcl_comm_patch_force_grid_indexed(h, list.data(), as_cells(field), count, 0));
+        OK(pcl_comm_step(h));
+    }
     OK(pcl_enable_step_diagnostics(h, 1));
     for (int s = 0; s < 30; ++s) OK(pcl_comm_step(h));
     pcl_diagnostics d;
@@ -501,5 +511,6 @@ int main()
         return 1;
     }
     std::printf("api_walk ok\n");
+    std::fflush(stdout);   // on record even if a library's exit handler ends the process
     return 0;
 }
