@@ -145,9 +145,9 @@ struct Comm {
     void* d_record = nullptr;          // 64-byte cursor record as broadcast
     // The root's records wait in pinned memory for their copy to the device, so that a brush event
     // never makes the host wait for the stream (the caller's record is only valid during the call):
-    // a ring of kRecordRing, a slot taken again once the copy made from it eight events ago has run.
+    // a ring of kRecordRing slots, each taken again once the copy made from it that many events ago has run.
     pcl_brush_input* h_records = nullptr;
-    hipEvent_t ev_record_copied[8] = {};
+    hipEvent_t ev_record_copied[kRecordRing] = {};
     int record_next = 0;
     char* d_stage = nullptr;           // indexed patches: cells then indices
     size_t stage_bytes = 0;
