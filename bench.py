@@ -25,7 +25,9 @@ this script's own timing exchange.  Rank 0 prints one JSON line.
 With N > 1 and no explicit workload flags the same invocation also times, after
 the headline, the weak-scaling case (2^28 particles on EVERY GPU) and, at
 N = 8, BASELINE configuration 4 (2^30 particles, diagnostics all-reduced every
-step); they appear under "also" in the line, never as "value".
+step); they appear under "also" in the line, never as "value", and cannot lose
+it: if they are not through after --also-timeout seconds the line is printed
+with the headline alone.
 ``--scaling weak|strong``, ``--particles-per-gpu``, ``--total-particles`` select
 one explicit case instead.
 """
@@ -33,6 +35,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -190,6 +193,9 @@ def main():
                     help="process-group backend (default: gloo with native collectives, where it is control plane only; "
                          "nccl with torch collectives).  torch collectives over gloo stage everything through the host "
                          "and admit several ranks on one GPU (a rehearsal of the multi-rank path on a one-GPU box)")
+    ap.add_argument("--also-timeout", type=float, default=240.0,
+                    help="N > 1 without workload flags: seconds the companion cases (weak scaling, configuration 4) may "
+                         "take after the headline before the line is printed without them")
     ap.add_argument("--force-collectives", action="store_true",
                     help="use the RCCL broadcast/all-reduce path even with one rank (when started by torch.distributed.run)")
     args = ap.parse_args()
@@ -238,10 +244,22 @@ def main():
                 "diag_on": args.diagnostics == "on", "with_cpu_baseline": world == 1 and not args.no_cpu_baseline}
     out = run_case(args, ctx, **headline)
     if world > 1 and not explicit and not args.edits:
+        # The headline is measured; the companion cases must not be able to lose it.  If they are not through after
+        # --also-timeout seconds (a rank stuck in a collective), rank 0 prints the line without them and every rank leaves.
+        def give_up():
+            if rank == 0:
+                out["also"] = {"error": f"the companion cases did not finish within {args.also_timeout:.0f} s; "
+                                        "the headline values of this line were complete before they started"}
+                os.write(json_fd, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+        watchdog = threading.Timer(args.also_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         also = {"weak_scaling": run_case(args, ctx, scaling="weak", n_total=(1 << 28) * world,
                                          diag_on=args.diagnostics == "on", with_cpu_baseline=False)}
         if world == 8:
             also["configuration_4"] = run_case(args, ctx, scaling="strong", n_total=1 << 30, diag_on=True, with_cpu_baseline=False)
+        watchdog.cancel()
         if rank == 0:
             out["also"] = {k: {f: v[f] for f in ("value", "unit", "ms_per_step", "scaling", "rccl_ranks",
                                                  "kernel_ms_per_rank", "config", "roofline", "final_diagnostics")}

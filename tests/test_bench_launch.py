@@ -98,6 +98,18 @@ def test_default_command_with_two_ranks_is_configuration_3_strong_with_its_compa
 
 
 @pytest.mark.gpu
+def test_companion_cases_that_do_not_finish_cannot_lose_the_headline():
+    """The same command with a time limit the companion cases cannot meet: the one JSON line still comes, with the
+    headline's values and an error where the companions would be, and the launcher ends with status 0."""
+    fake = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "libfake_rccl.so")
+    out = _run_and_parse(["--gpus", "2", "--steps", "3", "--warmup", "2", "--fused-steps", "0", "--also-timeout", "0.2"],
+                         env={"PCL_RCCL_LIBRARY": fake}, timeout=900)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["final_diagnostics"]["count"] == 1 << 28
+    assert "did not finish" in out["also"]["error"]
+
+
+@pytest.mark.gpu
 def test_plain_start_two_ranks_over_rccl():
     import torch
     if torch.cuda.device_count() < 2:
