@@ -659,6 +659,38 @@ def test_step_timing_reports_each_launch_and_its_kind():
         assert c.step_timing_read()[0].size == 9             # recording stopped: nothing new was appended
 
 
+def test_step_timing_of_a_one_kernel_step_is_the_kernels_own_time():
+    """From 2^23 particles on a plain step is one shaped launch, and step timing hands its two events to that launch
+    instead of recording them around it (tuning bit 0x800: recorded around every step).  Both ways: every launch has
+    a positive time and the right kind, the launch times add up to no more than the stopwatch around the region, and
+    the two ways agree on the plain kernel to a tenth."""
+    sp = pa.SimParams()
+    sp.delta_t = DT
+    sp.force_grid_dimensions = (256, 256, 1)
+    g = scene_swirl_field(256, 256, 1, 10.0, seed=2)
+    plain = {}
+    with pa.Compute.new(pa.empty_particles(0), g) as c:
+        c.update_sim_params(sp)
+        for variant in (0, 0x800):
+            c.set_tuning(0, variant)
+            c.generate_particles(1 << 23, seed=1, pos_extent=20.0)
+            c.set_reorder_interval(6)
+            for _ in range(3):
+                c.compute()                                   # the first sort and the clocks
+            c.step_timing_begin(12)
+            c.timer_start()
+            for _ in range(12):
+                c.compute()
+            region = c.timer_stop()
+            ms, kinds = c.step_timing_read()
+            assert ms.shape == (12,) and np.all(ms > 0), (variant, ms)
+            assert sorted(set(kinds.tolist())) == [1, 3, 4] and (kinds == 1).sum() == 8, kinds
+            assert ms.sum() <= region * 1.02, (variant, ms.sum(), region)
+            plain[variant] = float(ms[kinds == 1].mean())
+        assert c.launch_residency()["intended"] == 3          # the shaped launch it is about
+    assert abs(plain[0] - plain[0x800]) <= 0.1 * plain[0x800], plain
+
+
 # ---- cell-binned pair term: same terms, different summation order
 
 def _close(got, want, two_r, rtol=1e-5, atol=1e-6):
