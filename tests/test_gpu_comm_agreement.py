@@ -123,3 +123,68 @@ def test_ranks_agree_once_and_a_disagreement_is_an_error_on_every_rank(tmp_path)
         assert int(r["upload"]) == 4
         assert "step diagnostics are enabled on some ranks" in str(r["error"]), f"rank {rank}: {r['error']}"
         assert int(r["after"]) == 6    # the refused step asked, the step after it asked again
+
+
+def _worker_beside(rank, world, port, out_dir):
+    """Two ranks with step diagnostics on: after every pcl_comm_step the record that
+    pcl_comm_diagnostics_device points at, fetched through the handle's stream with no host
+    synchronisation in between, must be the record of ALL particles after that step."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["PCL_RCCL_LIBRARY"] = FAKE_RCCL
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import particles_amd as pa
+    from particles_amd import _lib
+    from oracle import oracle as O
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = _lib.load()
+        n, dims = 200_001, (32, 32, 1)
+        cells = dims[0] * dims[1]
+        g = np.ones((cells, 4), dtype=np.float32)
+        g[:, :3] = np.random.default_rng(8).uniform(-1, 1, size=(cells, 3)).astype(np.float32)
+        sp = pa.SimParams()
+        sp.delta_t = np.float32(1.0 / 60.0)
+        sp.force_grid_dimensions = dims
+        sp.masses = (1.0, 0.5, 2.0, 1.5, 0.75)
+        state = O.synth_particles(n, seed=5, pos_extent=20.0, vel_extent=10.0)
+        first, last = pa.shard_range(n, rank, world)
+        c = pa.Compute.new(state[first:last], g)
+        ids = [pa.Compute.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        c.comm_attach(ids[0], rank, world)
+        c.update_sim_params(sp)
+        c.set_reorder_interval(5)
+        c.enable_step_diagnostics(True)
+        keep = np.ascontiguousarray(g[cells - 3:])
+        worst = 0.0
+        for step in range(12):
+            c.comm_step()
+            rec = ctypes.c_void_p()
+            _lib.check(lib.pcl_comm_diagnostics_device(c._h, ctypes.byref(rec)))
+            _lib.check(lib.pcl_patch_force_grid_device(c._h, cells - 3, rec, 3))
+            d = _lib.Diagnostics.from_buffer_copy(c.read_force_grid(cells - 3, 3).tobytes())
+            _lib.check(lib.pcl_patch_force_grid(c._h, cells - 3, keep.ctypes.data_as(ctypes.c_void_p), 3))
+            state = O.step(sp, state, g, mode=O.MODE_SKIP_INERT)
+            want = O.diagnostics(sp, state)
+            assert int(d.count) == n, (rank, step, d.count)
+            assert np.array_equal(np.array(d.pos_max[:], dtype=np.float32), want["pos_max"]), (rank, step)
+            assert np.array_equal(-np.array(d.neg_pos_min[:], dtype=np.float32), want["pos_min"]), (rank, step)
+            worst = max(worst, abs(d.kinetic_energy - want["kinetic_energy"]) / want["kinetic_energy"])
+        assert worst <= 1e-11, worst
+        got = c.read_particles()
+        assert got.tobytes() == state[first:last].tobytes()
+        np.savez(os.path.join(out_dir, f"beside{rank}.npz"), worst=worst, steps=12)
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_the_all_reduce_beside_the_step_holds_the_global_record_of_that_step(tmp_path):
+    assert os.path.exists(FAKE_RCCL), "make builds tests/fake_rccl/libfake_rccl.so"
+    mp.spawn(_worker_beside, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        r = np.load(tmp_path / f"beside{rank}.npz")
+        assert int(r["steps"]) == 12 and float(r["worst"]) <= 1e-11
